@@ -1,0 +1,376 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the reference's (Samleo8/RadarSLAMPy) per-scan hot path, used as the
+checker in tests/, in __graft_entry__.smoke() and as bench.py's `cpu_baseline` leg.
+Nothing under radarslampy_amd/ imports this package; the product path has no CPU route.
+
+Layout
+  oracle/c/*.c      plain-C restatements (gcc -O2 -ffp-contract=off -> oracle/_build/liboracle.so)
+  oracle/__init__.py  ctypes wrappers with the reference's call signatures + the small
+                    numpy-only pieces (Kabsch, SE(2) helpers, feature dedupe, Tracker glue)
+
+Parity status (details in DESIGN.md §oracle):
+  PINNED by goldens produced by the reference itself (tests/golden/*.npz):
+      getPointCloudPolarInd, ssc, calculateTransformSVD, rejectOutliers (size always, set when
+      the maximum clique is unique), MotionDistortionSolver (error_vector, undistort,
+      compute_time_deltas, optimize_library), utils SE(2) helpers, record decode,
+      Tracker.track glue, Keyframe glue.
+  PARITY UNPINNED (OpenCV / scikit-image are un-vendored, absent, version-unpinned deps):
+      convertPolarImageToCartesian (cv2.warpPolar), getTrackedPointsKLT
+      (cv2.calcOpticalFlowPyrLK), getBlobsFromCart (skimage blob_doh) — restated from the
+      published algorithms with the reference's parameters; validated by known-answer tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+_LIB = os.path.join(_BUILD, "liboracle.so")
+_SRCS = ["peaks.c", "warp_klt.c", "clique.c", "lm.c", "ssc.c", "doh.c"]
+
+RANGE_RESOLUTION_M = 0.0432          # parseData.py:9
+RANGE_RESOLUTION_CART_M = 0.0864     # parseData.py:13
+MAX_RANGE_CLIP_PX = int(87.5 / RANGE_RESOLUTION_M)   # 2025, parseData.py:14,49-51
+DIST_THRESHOLD_PX = 0.5 / RANGE_RESOLUTION_CART_M    # outlierRejection.py:10-11
+ERR_THRESHOLD = 10                   # getTransformKLT.py:84
+RADAR_SCAN_FREQUENCY = 4             # motionDistortion.py:36
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/c/*.c into oracle/_build/liboracle.so (gcc only, a few seconds)."""
+    srcs = [os.path.join(_HERE, "c", s) for s in _SRCS if os.path.exists(os.path.join(_HERE, "c", s))]
+    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
+        return _LIB
+    os.makedirs(_BUILD, exist_ok=True)
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+           "-D_GNU_SOURCE", "-o", _LIB] + srcs + ["-lm"]
+    subprocess.run(cmd, check=True)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_peaks_f32.restype = C.c_int64
+        _lib.oracle_peaks_u8.restype = C.c_int64
+        _lib.oracle_pairwise_sum_f32.restype = C.c_float
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ------------------------------------------------------------------ a1: record decode
+def extractDataFromRadarImage(rec_u8: np.ndarray, maxRangeClipM: float = 87.5):
+    """parseData.py:17-53 (numpy restatement; same 6-tuple)."""
+    ts = rec_u8[:, :8].copy().view(np.int64)
+    az = (rec_u8[:, 8:10].copy().view(np.uint16) / float(5600) * 2 * np.pi).astype(np.float32)
+    valid = rec_u8[:, 10:11] == 255
+    data = rec_u8[:, 11:].astype(np.float32) / 255.
+    if maxRangeClipM > 0:
+        data = data[:, :int(maxRangeClipM / RANGE_RESOLUTION_M)]
+    return data, az, RANGE_RESOLUTION_M, az[1] - az[0], valid, ts
+
+
+# ------------------------------------------------------------------ a2: polar peaks
+def getPointCloudPolarInd(polarImage: np.ndarray) -> np.ndarray:
+    """getPointCloud.py:11-54 on the float32 polar image -> (P,2) int64 [azimuthIdx, rangeIdx]."""
+    img = np.ascontiguousarray(polarImage, dtype=np.float32)
+    rows, cols = img.shape
+    cap = rows * ((cols + 1) // 2)
+    out = np.empty((cap, 2), np.int32)
+    n = lib().oracle_peaks_f32(_p(img, C.c_float), rows, cols, C.c_int64(cols), _p(out, C.c_int32), C.c_int64(cap))
+    return out[:n].astype(np.int64)
+
+
+def peaks_from_record_u8(rec: np.ndarray, payload_off: int = 11, clip: int = MAX_RANGE_CLIP_PX) -> np.ndarray:
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    rows, stride = rec.shape
+    cap = rows * ((clip + 1) // 2)
+    out = np.empty((cap, 2), np.int32)
+    n = lib().oracle_peaks_u8(_p(rec, C.c_uint8), rows, C.c_int64(stride), payload_off, clip,
+                              _p(out, C.c_int32), C.c_int64(cap))
+    return out[:n].astype(np.int64)
+
+
+def pairwise_sum_f32(a: np.ndarray) -> np.float32:
+    a = np.ascontiguousarray(a, np.float32)
+    return np.float32(lib().oracle_pairwise_sum_f32(_p(a, C.c_float), C.c_int64(a.size)))
+
+
+# ------------------------------------------------------------------ a3: polar -> Cartesian
+def convertPolarImageToCartesian(imgPolar: np.ndarray, want_u8: bool = False):
+    """parseData.py:100-135 (downsampleFactor=2): (rows,cols) f32 -> (2R,2R) f32, R=cols//2."""
+    img = np.ascontiguousarray(imgPolar, dtype=np.float32)
+    rows, cols = img.shape
+    W = 2 * (cols // 2)
+    cart = np.empty((W, W), np.float32)
+    u8 = np.empty((W, W), np.uint8) if want_u8 else None
+    lib().oracle_polar_to_cart(_p(img, C.c_float), rows, cols, C.c_int64(cols), _p(cart, C.c_float),
+                               _p(u8, C.c_uint8) if want_u8 else None)
+    return (cart, u8) if want_u8 else cart
+
+
+def quantize_u8(img: np.ndarray) -> np.ndarray:
+    """(img*255).astype(np.uint8), getTransformKLT.py:356-357."""
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty(img.shape, np.uint8)
+    lib().oracle_quantize_u8(_p(img, C.c_float), C.c_int64(img.size), _p(out, C.c_uint8))
+    return out
+
+
+# ------------------------------------------------------------------ a7: pyramidal LK
+def build_pyramid(img_u8: np.ndarray, max_level: int = 3):
+    pyr = [np.ascontiguousarray(img_u8, np.uint8)]
+    for _ in range(max_level):
+        s = pyr[-1]
+        h, w = s.shape
+        d = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        lib().oracle_pyr_down_u8(_p(s, C.c_uint8), w, h, _p(d, C.c_uint8))
+        pyr.append(d)
+    return pyr
+
+
+def calcOpticalFlowPyrLK(prev_u8, next_u8, pts, winSize=15, maxLevel=3, maxCount=10, epsilon=0.03,
+                         minEigThreshold=1e-4):
+    """cv2.calcOpticalFlowPyrLK restatement -> (nextPts (K,2) f32, status (K,1) u8, err (K,1) f32)."""
+    pp, npyr = build_pyramid(prev_u8, maxLevel), build_pyramid(next_u8, maxLevel)
+    return klt_on_pyramids(pp, npyr, pts, winSize, maxCount, epsilon, minEigThreshold)
+
+
+def klt_on_pyramids(pp, npyr, pts, winSize=15, maxCount=10, epsilon=0.03, minEigThreshold=1e-4):
+    L = len(pp)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    K = pts.shape[0]
+    arr_t = C.POINTER(C.c_uint8) * L
+    P = arr_t(*[_p(a, C.c_uint8) for a in pp])
+    N = arr_t(*[_p(a, C.c_uint8) for a in npyr])
+    lw = (C.c_int * L)(*[a.shape[1] for a in pp])
+    lh = (C.c_int * L)(*[a.shape[0] for a in pp])
+    nxt = np.zeros((K, 2), np.float32)
+    st = np.zeros((K,), np.uint8)
+    err = np.zeros((K,), np.float32)
+    lib().oracle_klt_track(P, N, lw, lh, L, _p(pts, C.c_float), K, winSize, maxCount,
+                           C.c_float(epsilon), C.c_float(minEigThreshold),
+                           _p(nxt, C.c_float), _p(st, C.c_uint8), _p(err, C.c_float))
+    return nxt, st.reshape(-1, 1), err.reshape(-1, 1)
+
+
+def getTrackedPointsKLT(srcImg, targetImg, blobCoordSrc):
+    """getTransformKLT.py:317-381 without the internal re-detect branch (:348-352)."""
+    pts = np.ascontiguousarray(blobCoordSrc[:, :2]).astype(np.float32)
+    s8, t8 = quantize_u8(srcImg), quantize_u8(targetImg)
+    nxt, status, err = calcOpticalFlowPyrLK(s8, t8, pts)
+    status &= (err < ERR_THRESHOLD)
+    good = (status == 1).flatten()
+    return nxt[good], pts[good], nxt[~good], pts[~good], status
+
+
+# ------------------------------------------------------------------ a8: outlier rejection
+def consistency_graph(prev, new, thr=DIST_THRESHOLD_PX):
+    prev = np.ascontiguousarray(prev, np.float32)
+    new = np.ascontiguousarray(new, np.float32)
+    K = prev.shape[0]
+    nw = max(1, (K + 63) // 64)
+    adj = np.zeros((K, nw), np.uint64)
+    lib().oracle_consistency_graph(_p(prev, C.c_float), _p(new, C.c_float), K, C.c_double(thr),
+                                   _p(adj, C.c_uint64), nw)
+    return adj
+
+
+def max_clique_lex(adj: np.ndarray):
+    K, nw = adj.shape
+    mask = np.zeros(K, np.uint8)
+    nodes = C.c_int64(0)
+    size = lib().oracle_max_clique_lex(_p(np.ascontiguousarray(adj), C.c_uint64), K, nw,
+                                       _p(mask, C.c_uint8), C.byref(nodes))
+    return size, mask.astype(bool), nodes.value
+
+
+def rejectOutliers(prev_coord, new_coord):
+    """outlierRejection.py:16-95 -> (pruned_prev, pruned_new, mask bool (K,))."""
+    assert prev_coord.shape == new_coord.shape, "Coordinates should be the same shape"
+    K = prev_coord.shape[0]
+    if K == 0:
+        return prev_coord, new_coord, np.zeros(0, bool)
+    _, mask, _ = max_clique_lex(consistency_graph(prev_coord, new_coord))
+    return prev_coord[mask], new_coord[mask], mask
+
+
+def adjacency_dense(adj: np.ndarray, K: int) -> np.ndarray:
+    bits = np.unpackbits(adj.view(np.uint8), axis=1, bitorder="little")
+    return bits[:, :K].astype(bool)
+
+
+def max_clique_bruteforce(A: np.ndarray):
+    """Tiny independent checker: enumerate maximal cliques (Bron-Kerbosch with pivot, pure
+    Python) and return the lexicographically smallest maximum one.  Small K only."""
+    K = A.shape[0]
+    nb = [set(np.flatnonzero(A[i]).tolist()) - {i} for i in range(K)]
+    best = [[]]
+
+    def bk(R, P, X):
+        if not P and not X:
+            r = sorted(R)
+            if len(r) > len(best[0]) or (len(r) == len(best[0]) and r < best[0]):
+                best[0] = r
+            return
+        u = max(P | X, key=lambda v: len(P & nb[v]))
+        for v in list(P - nb[u]):
+            bk(R | {v}, P & nb[v], X & nb[v])
+            P.remove(v)
+            X.add(v)
+
+    bk(set(), set(range(K)), set())
+    m = np.zeros(K, bool)
+    m[best[0]] = True
+    return len(best[0]), m
+
+
+# ------------------------------------------------------------------ a10: 2-D Kabsch
+def calculateTransformSVD(srcCoords, targetCoords):
+    """getTransformKLT.py:129-162 restated in float64: src ~= R tgt + h.  (The reference
+    runs the same formulas in the input dtype; f32 inputs differ by ~3e-5 m)"""
+    s = np.asarray(srcCoords, np.float64)
+    t = np.asarray(targetCoords, np.float64)
+    ms, mt = s.mean(axis=0, keepdims=True), t.mean(axis=0, keepdims=True)
+    Cm = (s - ms).T @ (t - mt)
+    U, _, Vt = np.linalg.svd(Cm)
+    D = np.eye(2)
+    D[1, 1] = np.linalg.det(U @ Vt)
+    R = U @ D @ Vt
+    h = ms - (R @ mt.T).T
+    return R, h.T
+
+
+def kabsch_closed_form(src, tgt):
+    """Same fit without the SVD: theta = atan2(C01 - C10, C00 + C11) of C = sum (t-mt)(s-ms)^T
+    arrangement used by the device kernel; equals the SVD solution whenever C != 0."""
+    s = np.asarray(src, np.float64)
+    t = np.asarray(tgt, np.float64)
+    ms, mt = s.mean(axis=0), t.mean(axis=0)
+    a, b = s - ms, t - mt
+    sxx = (a[:, 0] * b[:, 0]).sum(); sxy = (a[:, 0] * b[:, 1]).sum()
+    syx = (a[:, 1] * b[:, 0]).sum(); syy = (a[:, 1] * b[:, 1]).sum()
+    th = np.arctan2(syx - sxy, sxx + syy)
+    c, sn = np.cos(th), np.sin(th)
+    R = np.array([[c, -sn], [sn, c]])
+    h = ms - R @ mt
+    return R, h.reshape(2, 1)
+
+
+# ------------------------------------------------------------------ a11-a14: motion distortion
+class MotionDistortionSolver:
+    """motionDistortion.py:38-325 (live 3-arg constructor :70-78)."""
+
+    def __init__(self, sigma_p, sigma_v, frequency=RADAR_SCAN_FREQUENCY):
+        self.total_scan_time = 1 / frequency
+        self.sigma_p = np.diag(sigma_p).astype(np.float64)
+        self.sigma_v = np.diag(sigma_v).astype(np.float64)
+
+    def update_problem(self, T_wj0, p_w, p_jt, T_wj, debug=False):
+        assert p_w.shape == p_jt.shape
+        self.T_wj0 = np.asarray(T_wj0, np.float64)
+        self.T_wj0_inv = np.linalg.inv(self.T_wj0)
+        self.p_w = np.ascontiguousarray(p_w[:, :2], np.float64)
+        self.p_jt = np.ascontiguousarray(p_jt[:, :2], np.float64)
+        self.T_wj_initial = np.ascontiguousarray(T_wj, np.float64)
+        self.dT = self.compute_time_deltas(self.total_scan_time, self.p_jt)
+
+    @staticmethod
+    def compute_time_deltas(period, points):
+        pts = np.ascontiguousarray(points[:, :2], np.float64)
+        dT = np.empty(pts.shape[0])
+        lib().oracle_time_deltas(_p(pts, C.c_double), pts.shape[0], C.c_double(period), _p(dT, C.c_double))
+        return dT
+
+    @staticmethod
+    def undistort(v_j, points, period=1 / RADAR_SCAN_FREQUENCY, times=None):
+        pts = np.ascontiguousarray(points[:, :2], np.float64)
+        v = np.ascontiguousarray(v_j, np.float64)
+        out = np.empty((pts.shape[0], 3))
+        xy = np.empty((pts.shape[0], 2))
+        lib().oracle_undistort(_p(v, C.c_double), _p(pts, C.c_double), pts.shape[0], C.c_double(period),
+                               _p(xy, C.c_double))
+        out[:, :2] = xy
+        out[:, 2] = 1.0
+        return out
+
+    def _solve(self, want_r0=False):
+        N = self.p_w.shape[0]
+        sig = np.concatenate((self.sigma_p, self.sigma_v)).astype(np.float64)
+        out = np.empty(6)
+        x0 = np.empty(6)
+        r0 = np.empty(2 * N + 3)
+        nfev = C.c_int(0)
+        T0 = np.ascontiguousarray(self.T_wj0)
+        info = lib().oracle_mds_solve(_p(T0, C.c_double), _p(self.p_w, C.c_double), _p(self.p_jt, C.c_double), N,
+                                      _p(self.T_wj_initial, C.c_double), _p(sig, C.c_double),
+                                      C.c_double(self.total_scan_time), _p(out, C.c_double), C.byref(nfev),
+                                      _p(x0, C.c_double), _p(r0, C.c_double))
+        self.nfev, self.info = nfev.value, info
+        return out, x0, r0
+
+    def optimize_library(self):
+        return self._solve()[0]
+
+
+# ------------------------------------------------------------------ a5/a6: ANMS + dedupe
+def ssc(keypoints, num_ret_points, tolerance, cols, rows):
+    """ANMS.py:5-102 -> selected rows of `keypoints` (same order)."""
+    kp = np.ascontiguousarray(keypoints, np.float64)
+    B = kp.shape[0]
+    sel = np.empty(max(B, 1), np.int32)
+    n = lib().oracle_ssc(_p(kp, C.c_double), B, int(num_ret_points), C.c_double(tolerance), int(cols), int(rows),
+                         _p(sel, C.c_int32))
+    return kp[sel[:n]]
+
+
+def adaptiveNMS(img_shape, blobs, ret_points=200, tolerance=0.1):
+    """getFeatures.py:66-72."""
+    H, W = img_shape
+    kp = blobs[np.argsort(blobs[:, 2])]
+    return ssc(kp, ret_points, tolerance, W, H)
+
+
+def append_dedupe(oldFeaturesCoord, newFeatureCoord):
+    """getFeatures.py:109-112: vstack, drop exact duplicate rows keeping first occurrence."""
+    pts = np.vstack((oldFeaturesCoord, newFeatureCoord))
+    _, idx = np.unique(pts, axis=0, return_index=True)
+    return np.ascontiguousarray(pts[np.sort(idx)]).astype(np.float32)
+
+
+# ------------------------------------------------------------------ SE(2) helpers (utils.py)
+def normalize_angles(th):
+    return (th + np.pi) % (2 * np.pi) - np.pi
+
+
+def convertPoseToTransform(pose):
+    x, y, th = pose
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c, -s, x], [s, c, y], [0, 0, 1.0]])
+
+
+def convertTransformToPose(T):
+    return np.array([T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])])
+
+
+# ------------------------------------------------------------------ a9: Tracker.track glue
+def track_glue(klt_out, do_reject=True):
+    """Tracker.py:75-104 given the 5-tuple of getTrackedPointsKLT."""
+    good_new, good_old, bad_new, bad_old, corrStatus = klt_out
+    nFeatures = good_new.shape[0] + bad_new.shape[0]
+    if do_reject:
+        good_old, good_new, mask = rejectOutliers(good_old, good_new)
+        rng = np.arange(nFeatures)
+        corrStatus = corrStatus.copy()
+        corrStatus[rng[corrStatus.flatten().astype(bool)]] &= mask[:, np.newaxis]
+    return good_old, good_new, 0.0, corrStatus
