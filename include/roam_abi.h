@@ -1,0 +1,194 @@
+/* roam_abi.h — C ABI of libroam_hip.so, the MI355X-native (gfx950, hand-written HIP)
+ * replacement for the per-scan hot path of Samleo8/RadarSLAMPy ("RAW-ROAM").
+ *
+ * The reference has no FFI: its "plugin API" is a set of Python call signatures.  Each
+ * entry point below states the reference callable it replaces (file:line, relative to the
+ * reference repo).  radarslampy_amd/_ffi.py binds exactly these symbols with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every function returns int32 status:
+ *     ROAM_OK (0) or a negative ROAM_E_* code; roam_last_error(ctx) has the text.
+ *   - The caller owns every host buffer.  Outputs go into caller-allocated, capacity-
+ *     checked arrays.  Device memory is owned by the context.
+ *   - Arrays are row-major contiguous.  Coordinates are [x, y] float32 pixels; poses are
+ *     [x, y, theta] float64; 3x3 transforms are row-major float64[9].
+ *   - One context = one GPU + one HIP stream; a context is single-threaded, distinct
+ *     contexts are independent.  No global mutable state.
+ *   - "stage" entry points take host arrays (H2D, kernel(s), D2H) and mirror one reference
+ *     function each.  "engine" entry points keep B independent sequences ("lanes")
+ *     resident in HBM and advance all of them by one scan pair per call without touching
+ *     the host (the throughput path measured by bench.py).
+ */
+#ifndef ROAM_ABI_H
+#define ROAM_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct roam_ctx roam_ctx;
+
+enum {
+    ROAM_OK = 0,
+    ROAM_E_ARG = -1,        /* bad argument (null pointer, size out of range)       */
+    ROAM_E_HIP = -2,        /* a HIP runtime call failed                              */
+    ROAM_E_CAPACITY = -3,   /* caller-provided output capacity too small             */
+    ROAM_E_NODEVICE = -4,   /* no usable gfx950 device                                */
+    ROAM_E_STATE = -5       /* engine call in the wrong state                         */
+};
+
+/* limits of this build */
+#define ROAM_MAX_FEATURES 1024      /* K_max per lane (KLT / graph / LM)                */
+#define ROAM_MAX_COLS 4096          /* longest polar row the peak kernel accepts        */
+#define ROAM_PYR_LEVELS 4           /* LK maxLevel=3 (getTransformKLT.py:77-81)         */
+
+/* ---- context ------------------------------------------------------------------------ */
+int32_t roam_create(int32_t device_id, roam_ctx **out);
+int32_t roam_destroy(roam_ctx *ctx);
+const char *roam_last_error(const roam_ctx *ctx);
+const char *roam_version(void);
+/* name_cap bytes for the device name; any out pointer may be NULL */
+int32_t roam_device_info(roam_ctx *ctx, char *name, int32_t name_cap, int32_t *cu_count,
+                         int64_t *hbm_bytes, char *arch, int32_t arch_cap);
+int32_t roam_synchronize(roam_ctx *ctx);
+
+/* ---- a2: getPointCloud.getPointCloudPolarInd (getPointCloud.py:11-54) ------------------
+ * polar: rows x cols float32.  out: (cap,2) int32 rows [azimuthIdx, rangeIdx], azimuth-
+ * major, range ascending.  *n_out = number of peaks found; if it exceeds cap the call
+ * returns ROAM_E_CAPACITY (the first cap pairs are valid). */
+int32_t roam_peaks_polar_f32(roam_ctx *ctx, const float *polar, int32_t rows, int32_t cols,
+                             int32_t *out, int64_t cap, int64_t *n_out);
+/* a1+a2 fused: raw Oxford record rows (parseData.extractDataFromRadarImage, parseData.py:17-53):
+ * value = rec[r*stride + payload_off + i] / 255 (float32), i < clip. */
+int32_t roam_peaks_record_u8(roam_ctx *ctx, const uint8_t *rec, int32_t rows, int64_t stride,
+                             int32_t payload_off, int32_t clip, int32_t *out, int64_t cap,
+                             int64_t *n_out);
+
+/* ---- a3: parseData.convertPolarImageToCartesian (parseData.py:100-135) -------------------
+ * polar rows x cols f32 -> (2R x 2R), R = cols/2.  cart_f32 and/or cart_u8 may be NULL;
+ * cart_u8 is the (img*255).astype(uint8) of getTransformKLT.py:356-357. */
+int32_t roam_polar_to_cart_f32(roam_ctx *ctx, const float *polar, int32_t rows, int32_t cols,
+                               float *cart_f32, uint8_t *cart_u8);
+int32_t roam_polar_to_cart_record_u8(roam_ctx *ctx, const uint8_t *rec, int32_t rows, int64_t stride,
+                                     int32_t payload_off, int32_t clip, float *cart_f32,
+                                     uint8_t *cart_u8);
+
+/* ---- a7: cv2.calcOpticalFlowPyrLK as used by getTransformKLT.getTrackedPointsKLT
+ * (getTransformKLT.py:317-381; LK_PARAMS :77-81: winSize 15, maxLevel 3, 10 iter, eps 0.03).
+ * Images are w x h; *_f32 variants quantise (img*255 -> u8, :356-357) on the device.
+ * pts (K,2) f32 -> next_pts (K,2) f32, status (K) u8, err (K) f32.  The reference's
+ * `status &= err < ERR_THRESHOLD` (:365) is applied by the caller. */
+int32_t roam_klt_track_u8(roam_ctx *ctx, const uint8_t *prev_img, const uint8_t *next_img,
+                          int32_t w, int32_t h, const float *pts, int32_t K,
+                          float *next_pts, uint8_t *status, float *err);
+int32_t roam_klt_track_f32(roam_ctx *ctx, const float *prev_img, const float *next_img,
+                           int32_t w, int32_t h, const float *pts, int32_t K,
+                           float *next_pts, uint8_t *status, float *err);
+/* pyrDown (5x5 Gaussian, REFLECT_101): src w x h -> dst ((w+1)/2 x (h+1)/2) */
+int32_t roam_pyr_down_u8(roam_ctx *ctx, const uint8_t *src, int32_t w, int32_t h, uint8_t *dst);
+
+/* ---- a8: outlierRejection.rejectOutliers (outlierRejection.py:16-95) --------------------
+ * prev/next (K,2) f32.  mask_out (K) u8 = membership of the maximum clique of the
+ * |d_prev - d_next| <= thr_px consistency graph (lexicographically smallest maximum clique
+ * when several exist).  node_limit bounds the branch-and-bound (0 = default);
+ * *flags_out bit0 = search completed (result proven maximum). adj_out (optional) receives
+ * the K x ((K+63)/64) uint64 adjacency bit rows. */
+int32_t roam_reject_outliers(roam_ctx *ctx, const float *prev, const float *next, int32_t K,
+                             double thr_px, int64_t node_limit, uint8_t *mask_out,
+                             int32_t *n_inliers, int32_t *flags_out, uint64_t *adj_out);
+
+/* ---- a10: getTransformKLT.calculateTransformSVD (getTransformKLT.py:129-162) -------------
+ * src ~= R tgt + h over N pairs of float64 [x,y]; R row-major [4], h [2]. */
+int32_t roam_kabsch2d(roam_ctx *ctx, const double *src, const double *tgt, int32_t N,
+                      double *R, double *h);
+
+/* ---- a11-a14: motionDistortion.MotionDistortionSolver (motionDistortion.py:70-205,295-325)
+ * update_problem + optimize_library in one call.  sigma5 = [sp_x, sp_y, sv_x, sv_y, sv_th]
+ * (covariance diagonals; residual weights are 1/sigma as in :96-99).  out6 = [v(3), pose(3)].
+ * x0_out (6) and r0_out (2N+3) are optional: start vector and error_vector(x0). */
+int32_t roam_mds_solve(roam_ctx *ctx, const double *T_wj0, const double *p_w, const double *p_jt,
+                       int32_t N, const double *T_wj_init, const double *sigma5, double period,
+                       double *out6, int32_t *nfev, int32_t *info, double *x0_out, double *r0_out);
+/* MotionDistortionSolver.undistort (:126-153) / compute_time_deltas (:107-124): pts (N,2) f64 */
+int32_t roam_mds_undistort(roam_ctx *ctx, const double *v3, const double *pts, int32_t N,
+                           double period, double *out_xy, double *dT_out);
+
+/* ---- a5: ANMS.ssc (ANMS.py:5-102) ----------------------------------------------------------
+ * kp (B,3) f64 rows [row, col, sigma] in priority order; sel_out (cap >= B) receives the
+ * selected indices in input order. */
+int32_t roam_ssc(roam_ctx *ctx, const double *kp, int32_t B, int32_t num_ret, double tol,
+                 int32_t cols, int32_t rows, int32_t *sel_out, int32_t *n_sel);
+
+/* ---- a4: getFeatures.getBlobsFromCart (skimage blob_doh, getFeatures.py:22-53) ------------
+ * img w x h f32 -> blobs (cap,3) f64 rows [row, col, sigma]. */
+int32_t roam_doh_blobs(roam_ctx *ctx, const float *img, int32_t w, int32_t h, double min_sigma,
+                       double max_sigma, int32_t num_sigma, double threshold, double overlap,
+                       double *blobs_out, int32_t cap, int32_t *n_out);
+
+/* ---- engine: B resident lanes, one scan pair per lane per step ---------------------------
+ * Replaces the body of the RawROAMSystem.run loop (RawROAMSystem.py:162-298) minus plotting:
+ * a1/a2 ingest+peaks, a3 warp+quantise, pyramid, a7 KLT against the lane's previous
+ * pyramid, status &= err<10, a8 outlier rejection, a10 Kabsch, a15 glue, a11-a14 LM,
+ * keyframe bookkeeping (Mapping.py:37-66,118-125,149-174). */
+typedef struct roam_engine_cfg {
+    int32_t lanes;            /* B                                                       */
+    int32_t rows;             /* 400                                                      */
+    int32_t stride;           /* 3779 bytes per record row                                */
+    int32_t payload_off;      /* 11                                                       */
+    int32_t clip;             /* 2025                                                     */
+    int32_t pool_scans;       /* number of raw records kept resident in HBM               */
+    int32_t peaks_cap;        /* per-lane capacity of the peak list                       */
+    int32_t reject_outliers;  /* paramFlags["rejectOutliers"] (Tracker.py:93)             */
+    int32_t motion_distortion;/* 1: LM pose (RawROAMSystem.py:208-237); 0: Kabsch dead reckoning (:236,301-317) */
+    int64_t clique_node_limit;
+    double sigma5[5];
+} roam_engine_cfg;
+
+typedef struct roam_lane_result {
+    double pose[3];           /* latest pose [x,y,th]                                    */
+    double velocity[3];
+    double kabsch_R[4];
+    double kabsch_h[2];       /* metres                                                   */
+    int32_t n_tracked;        /* K fed to KLT                                             */
+    int32_t n_good;           /* after status & err<10                                    */
+    int32_t n_inliers;        /* after outlier rejection                                  */
+    int32_t n_peaks;          /* polar peaks of the current scan                          */
+    int32_t lm_nfev;
+    int32_t lm_info;
+    int32_t flags;            /* bit0 clique proven, bit1 keyframe added, bit2 retrack wanted */
+    int32_t pad;
+} roam_lane_result;
+
+int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg);
+int32_t roam_engine_destroy(roam_ctx *ctx);
+/* copy one raw record (rows x stride u8) into pool slot idx */
+int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *rec);
+/* initialise a lane from a pool scan: pyramid of that scan becomes "previous", features =
+ * pts (K,2) f32 pixel [x,y], pose = pose3.  (First-frame feature detection is a4/a5.) */
+int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const float *pts,
+                              int32_t K, const double *pose3);
+/* advance every lane by one scan pair: lane i consumes pool scan scan_idx[i] as its current
+ * scan.  Asynchronous on the context stream. */
+int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx);
+/* blocking: fetch the per-lane results of the last step */
+int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
+/* blocking: current feature set of a lane (cap rows), and its peak list */
+int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t lane, float *pts, int32_t cap, int32_t *K);
+int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_t cap, int64_t *n);
+/* replace a lane's feature set (retrack append, getFeatures.appendNewFeatures getFeatures.py:98-118) */
+int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, int32_t K);
+/* per-stage device time of the last step in milliseconds (hipEvent pairs on the stream);
+ * names_out receives n pointers to static strings. */
+int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap,
+                                int32_t *n);
+/* time `reps` launches of the dominant streaming kernel (warp+quantise of all lanes) with
+ * HIP events on the context stream; returns average ms per launch. */
+int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms,
+                                double *algo_bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROAM_ABI_H */

@@ -1,0 +1,57 @@
+"""Build libroam_hip.so in-tree (radarslampy_amd/csrc/libroam_hip.so) with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container and the .so
+travels with the snapshot to the GPU box."""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libroam_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(out, deps):
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(CSRC, "roam_internal.h"), os.path.join(HERE, "..", "include", "roam_abi.h")]
+    objs, jobs = [], []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return cmd, r
+
+    with cf.ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        for cmd, r in ex.map(run, jobs):
+            if verbose or r.returncode != 0:
+                sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

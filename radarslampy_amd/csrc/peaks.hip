@@ -1,0 +1,256 @@
+// ingest + polar peak extraction (a1 + a2).
+//
+// Replaces getPointCloud.getPointCloudPolarInd (reference getPointCloud.py:11-54) fused with
+// the u8 -> float32 decode of parseData.extractDataFromRadarImage (parseData.py:40,49-51).
+//
+// One 256-thread workgroup per azimuth row (grid = rows x lanes): the row is staged once
+// through LDS (coalesced HBM read of the u8 payload / f32 row), every range bin is tested
+// for "left edge of a strict local maximum" (SciPy plateau rule: run of equal samples with
+// a strict rise before and a strict fall after, midpoint (l+r)/2, end samples never peaks),
+// candidates are compacted in range order with a ballot-free block scan, the float32
+// mean / population-std threshold is evaluated with NumPy's pairwise summation order
+// (blocks <= 128, 8 accumulators: leaves summed by independent threads, tree combined by
+// one) using IEEE round-to-nearest intrinsics (no FMA contraction), survivors are compacted
+// again and written as u16 range indices to a per-row staging area.  A second tiny kernel
+// turns the per-row counts into offsets and emits the azimuth-major (P,2) int32 list.
+//
+// HBM traffic per scan: rows*cols bytes read (u8 path) + ~4 B per surviving peak.
+#include "roam_internal.h"
+
+#define PK_T 256
+
+__device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; i++) {
+        int s = sh[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// NumPy pairwise_sum leaf (n <= 128), float32, round-to-nearest, no contraction
+__device__ __forceinline__ float np_leaf_sum(const float *a, int n)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res = __fadd_rn(res, a[i]);
+        return res;
+    }
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    const int nn = n - (n & 7);
+    for (i = 8; i < nn; i += 8) {
+        r0 = __fadd_rn(r0, a[i + 0]); r1 = __fadd_rn(r1, a[i + 1]);
+        r2 = __fadd_rn(r2, a[i + 2]); r3 = __fadd_rn(r3, a[i + 3]);
+        r4 = __fadd_rn(r4, a[i + 4]); r5 = __fadd_rn(r5, a[i + 5]);
+        r6 = __fadd_rn(r6, a[i + 6]); r7 = __fadd_rn(r7, a[i + 7]);
+    }
+    float res = __fadd_rn(__fadd_rn(__fadd_rn(r0, r1), __fadd_rn(r2, r3)),
+                          __fadd_rn(__fadd_rn(r4, r5), __fadd_rn(r6, r7)));
+    for (; i < n; i++) res = __fadd_rn(res, a[i]);
+    return res;
+}
+
+struct PwShared {
+    int leaf_lo[64];
+    int leaf_n[64];
+    float leaf_sum[64];
+    int stk_lo[12], stk_n[12], stk_state[12];
+    float stk_lv[12];
+    int nleaf;
+    float result;
+};
+
+// enumerate the leaves of NumPy's recursion for length n (thread 0), in order
+__device__ void pw_enumerate(PwShared *s, int n)
+{
+    int sp = 0, nl = 0;
+    s->stk_lo[0] = 0; s->stk_n[0] = n; s->stk_state[0] = 0;
+    while (sp >= 0) {
+        int cn = s->stk_n[sp], lo = s->stk_lo[sp];
+        if (cn <= 128) { s->leaf_lo[nl] = lo; s->leaf_n[nl] = cn; nl++; sp--; continue; }
+        int n2 = cn / 2; n2 -= n2 % 8;
+        int stt = s->stk_state[sp];
+        if (stt == 0) { s->stk_state[sp] = 1; s->stk_lo[sp + 1] = lo; s->stk_n[sp + 1] = n2; s->stk_state[sp + 1] = 0; sp++; }
+        else if (stt == 1) { s->stk_state[sp] = 2; s->stk_lo[sp + 1] = lo + n2; s->stk_n[sp + 1] = cn - n2; s->stk_state[sp + 1] = 0; sp++; }
+        else sp--;
+    }
+    s->nleaf = nl;
+}
+
+// combine leaf sums in recursion order (thread 0)
+__device__ float pw_combine(PwShared *s, int n)
+{
+    int sp = 0, li = 0;
+    float ret = 0.f;
+    s->stk_n[0] = n; s->stk_state[0] = 0;
+    while (sp >= 0) {
+        int cn = s->stk_n[sp];
+        if (cn <= 128) { ret = s->leaf_sum[li++]; sp--; continue; }
+        int n2 = cn / 2; n2 -= n2 % 8;
+        int stt = s->stk_state[sp];
+        if (stt == 0) { s->stk_state[sp] = 1; s->stk_n[sp + 1] = n2; s->stk_state[sp + 1] = 0; sp++; }
+        else if (stt == 1) { s->stk_lv[sp] = ret; s->stk_state[sp] = 2; s->stk_n[sp + 1] = cn - n2; s->stk_state[sp + 1] = 0; sp++; }
+        else { ret = __fadd_rn(s->stk_lv[sp], ret); sp--; }
+    }
+    return ret;
+}
+
+// block-wide NumPy-ordered float32 sum of a[0..n) (a in LDS); leaves must be enumerated
+__device__ float block_np_sum(PwShared *s, const float *a, int n)
+{
+    const int t = threadIdx.x;
+    if (t < s->nleaf) s->leaf_sum[t] = np_leaf_sum(a + s->leaf_lo[t], s->leaf_n[t]);
+    __syncthreads();
+    if (t == 0) s->result = pw_combine(s, n);
+    __syncthreads();
+    return s->result;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows, int cols,
+                                                          uint16_t *__restrict__ row_stage, int stage_cap,
+                                                          int32_t *__restrict__ row_count)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ PwShared pw;
+    __shared__ int scan_sh[8];
+    const int half = (cols + 1) / 2;
+    float *xs = reinterpret_cast<float *>(smem_raw);          // cols
+    float *ph = xs + cols;                                    // half
+    float *sq = ph + half;                                    // half
+    uint16_t *pm = reinterpret_cast<uint16_t *>(sq + half);   // half
+
+    const int b = blockIdx.y, r = blockIdx.x, t = threadIdx.x;
+    const int64_t lane_sel = src.lane_index ? (int64_t)src.lane_index[b] : (int64_t)b;
+    if (U8) {
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
+                           (int64_t)r * src.row_stride + src.payload_off;
+        for (int i = t; i < cols; i += PK_T) xs[i] = __fdiv_rn((float)p[i], 255.f);
+    } else {
+        const float *p = reinterpret_cast<const float *>(src.base) + lane_sel * src.lane_stride +
+                         (int64_t)r * src.row_stride;
+        for (int i = t; i < cols; i += PK_T) xs[i] = p[i];
+    }
+    __syncthreads();
+
+    // ---- strict local maxima (plateau rule), contiguous chunk per thread keeps range order
+    const int items = (cols + PK_T - 1) / PK_T;
+    const int lo = t * items, hi = min(lo + items, cols);
+    const int imax = cols - 1;
+    int cnt = 0;
+    for (int i = max(lo, 1); i < hi && i < imax; i++) {
+        float v = xs[i];
+        if (xs[i - 1] < v) {
+            int ia = i + 1;
+            while (ia < imax && xs[ia] == v) ia++;
+            if (xs[ia] < v) cnt++;
+        }
+    }
+    int M;
+    int pos = block_excl_scan(cnt, scan_sh, &M);
+    for (int i = max(lo, 1); i < hi && i < imax; i++) {
+        float v = xs[i];
+        if (xs[i - 1] < v) {
+            int ia = i + 1;
+            while (ia < imax && xs[ia] == v) ia++;
+            if (xs[ia] < v) {
+                int mid = (i + ia - 1) >> 1;
+                ph[pos] = xs[mid];
+                pm[pos] = (uint16_t)mid;
+                pos++;
+            }
+        }
+    }
+    if (M == 0) {                      // numpy: mean of empty = NaN -> nothing passes
+        if (t == 0) row_count[b * rows + r] = 0;
+        return;
+    }
+    if (t == 0) pw_enumerate(&pw, M);
+    __syncthreads();
+    const float fM = (float)M;
+    const float mean = __fdiv_rn(block_np_sum(&pw, ph, M), fM);
+    for (int k = t; k < M; k += PK_T) {
+        float d = __fsub_rn(ph[k], mean);
+        sq[k] = __fmul_rn(d, d);
+    }
+    __syncthreads();
+    const float var = __fdiv_rn(block_np_sum(&pw, sq, M), fM);
+    const float thr = __fadd_rn(mean, __fsqrt_rn(var));
+
+    // ---- threshold + ordered compaction
+    const int kitems = (M + PK_T - 1) / PK_T;
+    const int klo = t * kitems, khi = min(klo + kitems, M);
+    int c2 = 0;
+    for (int k = klo; k < khi; k++) c2 += (ph[k] >= thr) ? 1 : 0;
+    int total;
+    int p2 = block_excl_scan(c2, scan_sh, &total);
+    uint16_t *dst = row_stage + ((int64_t)b * rows + r) * stage_cap;
+    for (int k = klo; k < khi; k++)
+        if (ph[k] >= thr) {
+            if (p2 < stage_cap) dst[p2] = pm[k];
+            p2++;
+        }
+    if (t == 0) row_count[b * rows + r] = total;
+}
+
+// per lane: exclusive scan of row counts, then emit (az, rng) pairs azimuth-major
+__global__ __launch_bounds__(PK_T) void peaks_gather_kernel(const uint16_t *__restrict__ row_stage, int stage_cap,
+                                                            const int32_t *__restrict__ row_count, int rows,
+                                                            int32_t *__restrict__ out, int cap,
+                                                            int32_t *__restrict__ n_out)
+{
+    extern __shared__ int offs[];     // rows + 1
+    __shared__ int scan_sh[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int ritems = (rows + PK_T - 1) / PK_T;
+    const int lo = t * ritems, hi = min(lo + ritems, rows);
+    int c = 0;
+    for (int r = lo; r < hi; r++) c += min(row_count[b * rows + r], stage_cap);
+    int total;
+    int pos = block_excl_scan(c, scan_sh, &total);
+    for (int r = lo; r < hi; r++) { offs[r] = pos; pos += min(row_count[b * rows + r], stage_cap); }
+    if (t == 0) { offs[rows] = total; n_out[b] = total; }
+    __syncthreads();
+    const int lane = t & 63, w = t >> 6, nw = PK_T >> 6;
+    int32_t *o = out + (int64_t)b * cap * 2;
+    for (int r = w; r < rows; r += nw) {
+        const int off = offs[r], n = offs[r + 1] - off;
+        const uint16_t *s = row_stage + ((int64_t)b * rows + r) * stage_cap;
+        for (int j = lane; j < n; j += 64) {
+            int q = off + j;
+            if (q < cap) { o[2 * q] = r; o[2 * q + 1] = (int)s[j]; }
+        }
+    }
+}
+
+hipError_t launch_peaks(hipStream_t st, PeakSrc src, int B, int rows, int cols, uint16_t *row_stage,
+                        int stage_cap, int32_t *row_count, int32_t *out, int32_t cap, int32_t *n_out)
+{
+    const int half = (cols + 1) / 2;
+    size_t lds = sizeof(float) * (size_t)(cols + 2 * half) + sizeof(uint16_t) * (size_t)half + 16;
+    dim3 grid(rows, B), block(PK_T);
+    if (src.is_u8)
+        hipLaunchKernelGGL(peaks_rows_kernel<true>, grid, block, lds, st, src, rows, cols, row_stage, stage_cap, row_count);
+    else
+        hipLaunchKernelGGL(peaks_rows_kernel<false>, grid, block, lds, st, src, rows, cols, row_stage, stage_cap, row_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(peaks_gather_kernel, dim3(B), dim3(PK_T), sizeof(int) * (size_t)(rows + 1), st,
+                       row_stage, stage_cap, row_count, rows, out, cap, n_out);
+    return hipGetLastError();
+}

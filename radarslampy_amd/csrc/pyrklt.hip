@@ -1,0 +1,310 @@
+// Gaussian pyramid + pyramidal Lucas-Kanade tracking (a7).
+//
+// Replaces cv2.calcOpticalFlowPyrLK as called by getTransformKLT.getTrackedPointsKLT
+// (reference getTransformKLT.py:317-381; LK_PARAMS :77-81: winSize (15,15), maxLevel 3,
+// criteria (EPS|COUNT, 10, 0.03); default minEigThreshold 1e-4).  Algorithm statement and
+// what is (un)pinned: oracle/c/warp_klt.c.  Integer window sums are exact (int64), every
+// float operation is an explicit round-to-nearest intrinsic => bit-identical to the oracle.
+//
+// pyr_down: 256-thread block -> 64x16 output tile; the (131 x 35) u8 input tile is staged
+//   in LDS with REFLECT_101 addressing, filtered horizontally into LDS (u16), then
+//   vertically; one coalesced u8 store per output.  Reads each level once, writes once.
+// klt: ONE WAVEFRONT PER FEATURE (64-thread workgroup), all 4 levels in one launch.  Per
+//   level the 18x18 neighbourhood of the previous image is staged in LDS, Scharr
+//   derivatives are formed on the fly (never materialised in HBM: saves 2 x int16 x 4.1 MP
+//   per scan), the 15x15 patch (I, Ix, Iy) lives in registers (4 samples per lane), the
+//   2x2 normal matrix and the per-iteration mismatch vector are wave-wide integer
+//   reductions (DPP/shuffle butterflies), and the 16x16 window of the next image is
+//   re-staged per iteration (L2-resident).  Control flow is wave-uniform.
+#include "roam_internal.h"
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------ pyrDown
+#define PD_TW 64
+#define PD_TH 16
+#define PD_IW (2 * PD_TW + 3)   // 131
+#define PD_IH (2 * PD_TH + 3)   // 35
+#define PD_IWP 132
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int64_t src_lane_stride,
+                                                       int w, int h, uint8_t *__restrict__ dst,
+                                                       int64_t dst_lane_stride, int dw, int dh)
+{
+    __shared__ uint8_t tin[PD_IH][PD_IWP];
+    __shared__ uint16_t hb[PD_IH][PD_TW];
+    const int b = blockIdx.z;
+    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
+    const uint8_t *s = src + (int64_t)b * src_lane_stride;
+    const int t = threadIdx.x;
+    for (int i = t; i < PD_IH * PD_IW; i += 256) {
+        int ty = i / PD_IW, tx = i - ty * PD_IW;
+        int sy = reflect101(2 * oy0 - 2 + ty, h), sx = reflect101(2 * ox0 - 2 + tx, w);
+        tin[ty][tx] = s[(int64_t)sy * w + sx];
+    }
+    __syncthreads();
+    for (int i = t; i < PD_IH * PD_TW; i += 256) {
+        int ty = i / PD_TW, ox = i - ty * PD_TW;
+        const uint8_t *r = &tin[ty][2 * ox];
+        hb[ty][ox] = (uint16_t)(r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4]);
+    }
+    __syncthreads();
+    uint8_t *d = dst + (int64_t)b * dst_lane_stride;
+    for (int i = t; i < PD_TH * PD_TW; i += 256) {
+        int oy = i / PD_TW, ox = i - oy * PD_TW;
+        int X = ox0 + ox, Y = oy0 + oy;
+        if (X < dw && Y < dh) {
+            int acc = hb[2 * oy][ox] + 4 * hb[2 * oy + 1][ox] + 6 * hb[2 * oy + 2][ox] +
+                      4 * hb[2 * oy + 3][ox] + hb[2 * oy + 4][ox];
+            d[(int64_t)Y * dw + X] = (uint8_t)((acc + 128) >> 8);
+        }
+    }
+}
+
+hipError_t launch_pyr_down(hipStream_t st, const uint8_t *src, int64_t src_lane_stride, int w, int h,
+                           uint8_t *dst, int64_t dst_lane_stride, int B)
+{
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, B);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, st, src, src_lane_stride, w, h, dst, dst_lane_stride, dw, dh);
+    return hipGetLastError();
+}
+
+void pyr_desc_init(PyrDesc *d, int w, int h)
+{
+    int64_t off = 0;
+    for (int l = 0; l < ROAM_PYR_LEVELS; l++) {
+        d->w[l] = w; d->h[l] = h; d->off[l] = off;
+        off += (((int64_t)w * h) + 255) & ~(int64_t)255;      // keep levels 256-B aligned
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    d->lane_stride = off;
+}
+
+hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, int B)
+{
+    for (int l = 0; l + 1 < ROAM_PYR_LEVELS; l++) {
+        hipError_t e = launch_pyr_down(st, pyr + d.off[l], d.lane_stride, d.w[l], d.h[l],
+                                       pyr + d.off[l + 1], d.lane_stride, B);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------ KLT
+#define KW 15
+#define W_BITS 14
+#define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        int lo = __shfl_xor((int)(v & 0xffffffffll), m);
+        int hi = __shfl_xor((int)(v >> 32), m);
+        v += ((long long)hi << 32) | (unsigned int)lo;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void bilin_weights(float a, float b, int &iw00, int &iw01, int &iw10, int &iw11)
+{
+    const float S = (float)(1 << W_BITS);
+    const float na = __fsub_rn(1.f, a), nb = __fsub_rn(1.f, b);
+    iw00 = __float2int_rn(__fmul_rn(__fmul_rn(na, nb), S));
+    iw01 = __float2int_rn(__fmul_rn(__fmul_rn(a, nb), S));
+    iw10 = __float2int_rn(__fmul_rn(__fmul_rn(na, b), S));
+    iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+}
+
+__global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ prev_pyr,
+                                                 const uint8_t *__restrict__ next_pyr, PyrDesc d,
+                                                 const float *__restrict__ pts, const int32_t *__restrict__ count,
+                                                 int kstride, float *__restrict__ next_out,
+                                                 uint8_t *__restrict__ status_out, float *__restrict__ err_out)
+{
+    __shared__ short It[18][18];
+    __shared__ short Dx[16][16], Dy[16][16];
+    __shared__ short Jt[16][17];
+    const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (count && k >= count[b]) return;
+    const int64_t pidx = ((int64_t)b * kstride + k) * 2;
+    const float ptx = pts[pidx], pty = pts[pidx + 1];
+    const float halfWin = 7.f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps2 = __fmul_rn(0.03f, 0.03f);
+    const float min_eig_thr = 1e-4f;
+    float out_x = 0.f, out_y = 0.f, er = 0.f;
+    int st = 1;
+
+    // patch sample coordinates owned by this lane
+    int py_[4], px_[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int p = lane + 64 * q;
+        py_[q] = p / KW; px_[q] = p - py_[q] * KW;
+    }
+
+    for (int level = ROAM_PYR_LEVELS - 1; level >= 0; level--) {
+        const int w = d.w[level], h = d.h[level];
+        const uint8_t *I = prev_pyr + (int64_t)b * d.lane_stride + d.off[level];
+        const uint8_t *J = next_pyr + (int64_t)b * d.lane_stride + d.off[level];
+        const float scale = 1.f / (float)(1 << level);
+        float px = __fmul_rn(ptx, scale), py = __fmul_rn(pty, scale);
+        float nx, ny;
+        if (level == ROAM_PYR_LEVELS - 1) { nx = px; ny = py; }
+        else { nx = __fmul_rn(out_x, 2.f); ny = __fmul_rn(out_y, 2.f); }
+        out_x = nx; out_y = ny;
+        px = __fsub_rn(px, halfWin); py = __fsub_rn(py, halfWin);
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -KW || ipx >= w || ipy < -KW || ipy >= h) {
+            if (level == 0) { st = 0; er = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        bilin_weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy), iw00, iw01, iw10, iw11);
+
+        __syncthreads();
+        for (int i = lane; i < 18 * 18; i += 64) {
+            int ty = i / 18, tx = i - ty * 18;
+            It[ty][tx] = (short)I[(int64_t)reflect101(ipy - 1 + ty, h) * w + reflect101(ipx - 1 + tx, w)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int i = lane + 64 * q;
+            int y = i >> 4, x = i & 15;
+            int X = ipx + x, Y = ipy + y;
+            int dx = 0, dy = 0;
+            if (X >= 0 && Y >= 0 && X < w && Y < h) {
+                int a00 = It[y][x], a01 = It[y][x + 1], a02 = It[y][x + 2];
+                int a10 = It[y + 1][x], a12 = It[y + 1][x + 2];
+                int a20 = It[y + 2][x], a21 = It[y + 2][x + 1], a22 = It[y + 2][x + 2];
+                dx = 3 * (a02 + a22 - a00 - a20) + 10 * (a12 - a10);
+                dy = 3 * (a20 + a22 - a00 - a02) + 10 * (a21 - a01);
+            }
+            Dx[y][x] = (short)dx; Dy[y][x] = (short)dy;
+        }
+        __syncthreads();
+        int Iv[4], Ix[4], Iy[4];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            Iv[q] = 0; Ix[q] = 0; Iy[q] = 0;
+            if (lane + 64 * q < KW * KW) {
+                int y = py_[q], x = px_[q];
+                Iv[q] = DESCALE(It[y + 1][x + 1] * iw00 + It[y + 1][x + 2] * iw01 + It[y + 2][x + 1] * iw10 + It[y + 2][x + 2] * iw11, W_BITS - 5);
+                Ix[q] = DESCALE(Dx[y][x] * iw00 + Dx[y][x + 1] * iw01 + Dx[y + 1][x] * iw10 + Dx[y + 1][x + 1] * iw11, W_BITS);
+                Iy[q] = DESCALE(Dy[y][x] * iw00 + Dy[y][x + 1] * iw01 + Dy[y + 1][x] * iw10 + Dy[y + 1][x + 1] * iw11, W_BITS);
+                sA11 += (long long)Ix[q] * Ix[q];
+                sA12 += (long long)Ix[q] * Iy[q];
+                sA22 += (long long)Iy[q] * Iy[q];
+            }
+        }
+        sA11 = wave_sum_ll(sA11); sA12 = wave_sum_ll(sA12); sA22 = wave_sum_ll(sA22);
+        const float A11 = __fmul_rn(__ll2float_rn(sA11), FLT_SCALE);
+        const float A12 = __fmul_rn(__ll2float_rn(sA12), FLT_SCALE);
+        const float A22 = __fmul_rn(__ll2float_rn(sA22), FLT_SCALE);
+        float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+        const float dA = __fsub_rn(A11, A22);
+        const float minEig = __fdiv_rn(
+            __fsub_rn(__fadd_rn(A22, A11),
+                      __fsqrt_rn(__fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
+            (float)(2 * KW * KW));
+        if (minEig < min_eig_thr || D < 1.1920929e-07f) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = __fdiv_rn(1.f, D);
+        nx = __fsub_rn(nx, halfWin); ny = __fsub_rn(ny, halfWin);
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < 10; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -KW || inx >= w || iny < -KW || iny >= h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            bilin_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny), iw00, iw01, iw10, iw11);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int i = lane + 64 * q;
+                int y = i >> 4, x = i & 15;
+                Jt[y][x] = (short)J[(int64_t)reflect101(iny + y, h) * w + reflect101(inx + x, w)];
+            }
+            __syncthreads();
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (lane + 64 * q < KW * KW) {
+                    int y = py_[q], x = px_[q];
+                    int jv = DESCALE(Jt[y][x] * iw00 + Jt[y][x + 1] * iw01 + Jt[y + 1][x] * iw10 + Jt[y + 1][x + 1] * iw11, W_BITS - 5);
+                    int diff = jv - Iv[q];
+                    sb1 += (long long)diff * Ix[q];
+                    sb2 += (long long)diff * Iy[q];
+                }
+            sb1 = wave_sum_ll(sb1); sb2 = wave_sum_ll(sb2);
+            const float b1 = __fmul_rn(__ll2float_rn(sb1), FLT_SCALE);
+            const float b2 = __fmul_rn(__ll2float_rn(sb2), FLT_SCALE);
+            const float ddx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), D);
+            const float ddy = __fmul_rn(__fsub_rn(__fmul_rn(A12, b1), __fmul_rn(A11, b2)), D);
+            nx = __fadd_rn(nx, ddx); ny = __fadd_rn(ny, ddy);
+            out_x = __fadd_rn(nx, halfWin); out_y = __fadd_rn(ny, halfWin);
+            if (__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)) <= eps2) break;
+            if (j > 0 && fabsf(__fadd_rn(ddx, pdx)) < 0.01f && fabsf(__fadd_rn(ddy, pdy)) < 0.01f) {
+                out_x = __fsub_rn(out_x, __fmul_rn(ddx, 0.5f));
+                out_y = __fsub_rn(out_y, __fmul_rn(ddy, 0.5f));
+                break;
+            }
+            pdx = ddx; pdy = ddy;
+        }
+        if (st && level == 0) {
+            const float ex = __fsub_rn(out_x, halfWin), ey = __fsub_rn(out_y, halfWin);
+            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            if (iex < -KW || iex >= w || iey < -KW || iey >= h) { st = 0; continue; }
+            bilin_weights(__fsub_rn(ex, (float)iex), __fsub_rn(ey, (float)iey), iw00, iw01, iw10, iw11);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int i = lane + 64 * q;
+                int y = i >> 4, x = i & 15;
+                Jt[y][x] = (short)J[(int64_t)reflect101(iey + y, h) * w + reflect101(iex + x, w)];
+            }
+            __syncthreads();
+            long long se = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (lane + 64 * q < KW * KW) {
+                    int y = py_[q], x = px_[q];
+                    int jv = DESCALE(Jt[y][x] * iw00 + Jt[y][x + 1] * iw01 + Jt[y + 1][x] * iw10 + Jt[y + 1][x + 1] * iw11, W_BITS - 5);
+                    int diff = jv - Iv[q];
+                    se += diff < 0 ? -diff : diff;
+                }
+            se = wave_sum_ll(se);
+            er = __fmul_rn(__ll2float_rn(se), 1.f / (float)(32 * KW * KW));
+        }
+    }
+    if (lane == 0) {
+        next_out[pidx] = out_x; next_out[pidx + 1] = out_y;
+        status_out[(int64_t)b * kstride + k] = (uint8_t)st;
+        err_out[(int64_t)b * kstride + k] = er;
+    }
+}
+
+hipError_t launch_klt(hipStream_t st, const uint8_t *prev_pyr, const uint8_t *next_pyr,
+                      const PyrDesc &d, const float *pts, const int32_t *count, int K, int kstride,
+                      int B, float *next, uint8_t *status, float *err)
+{
+    if (K <= 0 || B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(klt_kernel, dim3(K, B), dim3(64), 0, st, prev_pyr, next_pyr, d, pts, count, kstride,
+                       next, status, err);
+    return hipGetLastError();
+}

@@ -1,0 +1,159 @@
+// polar -> Cartesian warp + u8 quantisation (a3, feeds a7).
+//
+// Replaces parseData.convertPolarImageToCartesian (reference parseData.py:100-135, i.e.
+// cv2.warpPolar with WARP_POLAR_LINEAR|WARP_INVERSE_MAP|INTER_LINEAR|WARP_FILL_OUTLIERS)
+// and the (img*255).astype(uint8) of getTransformKLT.py:356-357, fused: the f32 Cartesian
+// image (16.4 MB) is only materialised when the caller asks for it.
+//
+// Arithmetic follows the published OpenCV pipeline operation by operation (see
+// oracle/c/warp_klt.c for the statement of what is and is not pinned): float maps from
+// sqrt + the degree-7 fastAtan polynomial, double-precision scale, 1/32-pixel coordinate
+// rounding (round-half-even), table-equivalent bilinear weights, zero fill in range, wrap
+// in azimuth.  Everything is written with IEEE round-to-nearest intrinsics so that the
+// compiler cannot contract a*b+c into an FMA: results are bit-identical to the oracle.
+//
+// Layout: one thread produces 4 consecutive output pixels of one row and stores them as a
+// single 32-bit word (u8) / 128-bit vector (f32): 256-thread blocks, grid = (ceil(W/4/256),
+// W, lanes).  The polar source (0.8 MB u8 per scan) is gathered through L2.
+#include "roam_internal.h"
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float R2D = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * R2D;
+    const float p3 = -0.3258083974640975f * R2D;
+    const float p5 = 0.1555786518463281f * R2D;
+    const float p7 = -0.04432655554792128f * R2D;
+    const float DE = (float)2.220446049250313e-16;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, DE));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, DE));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+template <bool U8>
+__device__ __forceinline__ float polar_tap(const void *base, int64_t row_stride, int payload_off,
+                                           int rows, int cols, int py, int px)
+{
+    if (px < 0 || px >= cols || py < 0 || py >= rows + 2) return 0.f;
+    int r = py - 1;
+    if (r < 0) r += rows;
+    else if (r >= rows) r -= rows;
+    if (U8) {
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(base) + (int64_t)r * row_stride + payload_off;
+        return __fdiv_rn((float)p[px], 255.f);
+    } else {
+        const float *p = reinterpret_cast<const float *>(base) + (int64_t)r * row_stride;
+        return p[px];
+    }
+}
+
+template <bool U8>
+__device__ __forceinline__ float warp_pixel(const void *base, int64_t row_stride, int payload_off,
+                                            int rows, int cols, int R, double Kangle, double Kmag,
+                                            int x, int y)
+{
+    const float fx = __fsub_rn((float)x, (float)R);
+    const float fy = __fsub_rn((float)y, (float)R);
+    const float mag = __fsqrt_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)));
+    const float ang = __fmul_rn(fast_atan2_deg(fy, fx), (float)(3.14159265358979323846 / 180.0));
+    const double rho = __ddiv_rn((double)mag, Kmag);
+    const double phi = __ddiv_rn((double)ang, Kangle);
+    const float mx = (float)rho;
+    const float my = __fadd_rn((float)phi, 1.f);
+    const int sx = __float2int_rn(__fmul_rn(mx, 32.f));
+    const int sy = __float2int_rn(__fmul_rn(my, 32.f));
+    const int ix = sx >> 5, iy = sy >> 5;
+    const float wx1 = __fmul_rn((float)(sx & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+    const float wy1 = __fmul_rn((float)(sy & 31), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+    const float w00 = __fmul_rn(wy0, wx0), w01 = __fmul_rn(wy0, wx1);
+    const float w10 = __fmul_rn(wy1, wx0), w11 = __fmul_rn(wy1, wx1);
+    const float s00 = polar_tap<U8>(base, row_stride, payload_off, rows, cols, iy, ix);
+    const float s01 = polar_tap<U8>(base, row_stride, payload_off, rows, cols, iy, ix + 1);
+    const float s10 = polar_tap<U8>(base, row_stride, payload_off, rows, cols, iy + 1, ix);
+    const float s11 = polar_tap<U8>(base, row_stride, payload_off, rows, cols, iy + 1, ix + 1);
+    float v = __fmul_rn(s00, w00);
+    v = __fadd_rn(v, __fmul_rn(s01, w01));
+    v = __fadd_rn(v, __fmul_rn(s10, w10));
+    v = __fadd_rn(v, __fmul_rn(s11, w11));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t quant_u8(float v)
+{
+    return (uint32_t)(int)__fmul_rn(v, 255.f) & 0xffu;       // (img*255).astype(uint8): truncation
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void polar_to_cart_kernel(WarpSrc src, int rows, int cols, int R,
+                                                            uint8_t *__restrict__ cart_u8, int64_t u8_lane_stride,
+                                                            float *__restrict__ cart_f32, int64_t f32_lane_stride)
+{
+    const int W = 2 * R;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x0 >= W) return;
+    const int64_t lane_sel = src.lane_index ? (int64_t)src.lane_index[b] : (int64_t)b;
+    const void *base = U8 ? (const void *)(reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride)
+                          : (const void *)(reinterpret_cast<const float *>(src.base) + lane_sel * src.lane_stride);
+    const double Kangle = 6.283185307179586476925286766559 / (double)rows;
+    const double Kmag = (double)R / (double)cols;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        v[k] = (x0 + k < W) ? warp_pixel<U8>(base, src.row_stride, src.payload_off, rows, cols, R, Kangle, Kmag, x0 + k, y) : 0.f;
+    if (cart_f32) {
+        float *o = cart_f32 + (int64_t)b * f32_lane_stride + (int64_t)y * W + x0;
+        if (x0 + 3 < W && ((W & 3) == 0)) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int k = 0; k < 4 && x0 + k < W; k++) o[k] = v[k];
+    }
+    if (cart_u8) {
+        uint8_t *o = cart_u8 + (int64_t)b * u8_lane_stride + (int64_t)y * W + x0;
+        if (x0 + 3 < W && ((W & 3) == 0) && ((u8_lane_stride & 3) == 0)) {
+            uint32_t pk = quant_u8(v[0]) | (quant_u8(v[1]) << 8) | (quant_u8(v[2]) << 16) | (quant_u8(v[3]) << 24);
+            *reinterpret_cast<uint32_t *>(o) = pk;
+        } else
+            for (int k = 0; k < 4 && x0 + k < W; k++) o[k] = (uint8_t)quant_u8(v[k]);
+    }
+}
+
+hipError_t launch_polar_to_cart(hipStream_t st, WarpSrc src, int B, int rows, int cols,
+                                uint8_t *cart_u8, int64_t u8_lane_stride, float *cart_f32,
+                                int64_t f32_lane_stride)
+{
+    const int R = cols / 2, W = 2 * R;
+    dim3 grid((W / 4 + 255) / 256 + ((W % 4) ? 1 : 0), W, B), block(256);
+    if (src.is_u8)
+        hipLaunchKernelGGL(polar_to_cart_kernel<true>, grid, block, 0, st, src, rows, cols, R, cart_u8, u8_lane_stride, cart_f32, f32_lane_stride);
+    else
+        hipLaunchKernelGGL(polar_to_cart_kernel<false>, grid, block, 0, st, src, rows, cols, R, cart_u8, u8_lane_stride, cart_f32, f32_lane_stride);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void quantize_u8_kernel(const float *__restrict__ img, int64_t n, uint8_t *__restrict__ out)
+{
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(img) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0)) {
+        float4 v = *reinterpret_cast<const float4 *>(img + i);
+        uint32_t pk = quant_u8(v.x) | (quant_u8(v.y) << 8) | (quant_u8(v.z) << 16) | (quant_u8(v.w) << 24);
+        *reinterpret_cast<uint32_t *>(out + i) = pk;
+    } else
+        for (int k = 0; k < 4 && i + k < n; k++) out[i + k] = (uint8_t)quant_u8(img[i + k]);
+}
+
+hipError_t launch_quantize_u8(hipStream_t st, const float *img, int64_t n, uint8_t *out)
+{
+    int64_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, n, out);
+    return hipGetLastError();
+}
