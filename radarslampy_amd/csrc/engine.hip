@@ -1,16 +1,615 @@
-// engine: placeholder until the batched lane pipeline lands (next commit)
+// Batched, device-resident scan-pair engine.
+//
+// B independent sequences ("lanes") live in HBM: the raw Oxford records (pool), two
+// u8 pyramids per lane (previous / current, ping-pong), the tracked feature set, the
+// keyframe state and the poses.  One roam_engine_step() advances EVERY lane by one scan
+// pair with ~15 kernel launches on one stream and no host round trip:
+//   ingest+peaks -> warp+quantise -> pyramid -> KLT -> (status & err<10) compaction ->
+//   consistency graph -> max clique -> inlier compaction + keyframe pruning + p_w / p_jt ->
+//   Kabsch -> initial transform -> motion-distortion LM -> pose / keyframe bookkeeping.
+// It restates the body of RawROAMSystem.run's loop (reference RawROAMSystem.py:162-298)
+// without the plotting, Tracker.track (Tracker.py:35-106) and the Keyframe bookkeeping
+// (Mapping.py:37-66,97-125,149-174).  Scan pairs of different lanes are independent, so the
+// batch dimension is what fills the 256 CUs; within a lane the chain is sequential.
 #include "roam_internal.h"
-extern "C" {
-int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *) { if (!ctx) return ROAM_E_ARG; ROAM_SET_ERR(ctx, "engine not built"); return ROAM_E_STATE; }
-int32_t roam_engine_destroy(roam_ctx *ctx) { return ctx ? ROAM_OK : ROAM_E_ARG; }
-int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t, const uint8_t *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t, int32_t, const float *, int32_t, const double *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_step(roam_ctx *ctx, const int32_t *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *, int32_t) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t, float *, int32_t, int32_t *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t, int32_t *, int64_t, int64_t *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_set_features(roam_ctx *ctx, int32_t, const float *, int32_t) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_stage_times(roam_ctx *ctx, float *, const char **, int32_t, int32_t *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *, int32_t, float *, double *) { return ctx ? ROAM_E_STATE : ROAM_E_ARG; }
-int32_t roam_doh_blobs(roam_ctx *ctx, const float *, int32_t, int32_t, double, double, int32_t, double, double, double *, int32_t, int32_t *) { if (!ctx) return ROAM_E_ARG; ROAM_SET_ERR(ctx, "doh not built"); return ROAM_E_STATE; }
+#include <new>
+#include <chrono>
+
+#define KS ROAM_MAX_FEATURES
+#define CART_CENTER 1012.0
+#define M_PER_PX 0.0864
+#define N_RETRACK 60             // getFeatures.py:57 (import-time binding used by RawROAMSystem.py:7,251)
+#define ROT_THR 0.2              // Mapping.py:13
+#define TRANS_THR_SQ 4.0         // Mapping.py:14-15
+#define ERR_THR 10.0f            // getTransformKLT.py:84
+#define TWO_PI 6.283185307179586476925286766559
+
+enum { ST_PEAKS = 0, ST_WARP, ST_PYR, ST_KLT, ST_GRAPH, ST_CLIQUE, ST_KABSCH, ST_LM, ST_GLUE, ST_COUNT };
+static const char *kStageNames[ST_COUNT] = {"ingest_peaks", "warp_quantise", "pyramid", "klt", "consistency_graph",
+                                            "max_clique", "kabsch", "mds_lm", "glue"};
+
+struct Engine {
+    roam_engine_cfg cfg;
+    int B = 0, W = 0, stage_cap = 0;
+    PyrDesc pd;
+    size_t rec_bytes = 0;
+    uint8_t *pool = nullptr;
+    uint8_t *pyr[2] = {nullptr, nullptr};
+    int cur = 0;                        // pyr[cur] = previous image pyramids
+    uint16_t *row_stage = nullptr;
+    int32_t *row_count = nullptr, *peaks_out = nullptr, *peaks_n = nullptr;
+    int32_t *scan_idx = nullptr;
+    float *feat = nullptr;              // B x KS x 2
+    int32_t *feat_n = nullptr;
+    float *klt_next = nullptr, *klt_err = nullptr;
+    uint8_t *klt_status = nullptr;
+    float *good_old = nullptr, *good_new = nullptr;
+    int32_t *good_idx = nullptr, *good_n = nullptr;
+    uint64_t *adj = nullptr, *cq_stack = nullptr;
+    uint8_t *cq_mask = nullptr;
+    int32_t *cq_n = nullptr, *cq_flags = nullptr;
+    double *kab_src = nullptr, *kab_tgt = nullptr, *kab_out = nullptr;
+    int32_t *in_n = nullptr;
+    double *kf_pose = nullptr, *kf_und = nullptr, *kf_und_tmp = nullptr;   // B x 3, B x KS x 2
+    double *pose = nullptr, *vel = nullptr;                                // B x 3
+    double *T_wj0 = nullptr, *T_init = nullptr, *p_w = nullptr, *p_jt = nullptr;
+    double *lm_work = nullptr, *lm_out = nullptr;
+    int32_t *lm_nfev = nullptr, *lm_info = nullptr;
+    roam_lane_result *results = nullptr;
+    hipEvent_t ev[ST_COUNT + 1];
+    bool ev_ok = false, stepped = false;
+    std::vector<void *> allocs;
+};
+
+template <typename T>
+static bool dalloc(roam_ctx *ctx, Engine *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    hipError_t err = hipMalloc(&q, bytes);
+    if (err != hipSuccess) {
+        ROAM_SET_ERR(ctx, "engine: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return false;
+    }
+    hipMemsetAsync(q, 0, bytes, ctx->stream);
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return true;
 }
+
+// ------------------------------------------------------------------------------ glue kernels
+__device__ __forceinline__ int blk_excl_scan(int v, int *sh, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
+    }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; i++) {
+        int s = sh[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// G1: status &= err < ERR_THRESHOLD (getTransformKLT.py:365), ordered compaction of the good pairs
+__global__ __launch_bounds__(256) void g1_good_kernel(const float *__restrict__ feat, const int32_t *__restrict__ feat_n,
+                                                      const float *__restrict__ klt_next, uint8_t *__restrict__ status,
+                                                      const float *__restrict__ err, float *__restrict__ good_old,
+                                                      float *__restrict__ good_new, int32_t *__restrict__ good_idx,
+                                                      int32_t *__restrict__ good_n)
+{
+    __shared__ int sh[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int K = feat_n[b];
+    const int items = (KS + 255) / 256;
+    const int lo = t * items, hi = min(lo + items, K);
+    int c = 0;
+    for (int k = lo; k < hi; k++) {
+        const int64_t i = (int64_t)b * KS + k;
+        uint8_t s = status[i] & (uint8_t)(err[i] < ERR_THR);
+        status[i] = s;
+        c += s;
+    }
+    int total;
+    int pos = blk_excl_scan(c, sh, &total);
+    for (int k = lo; k < hi; k++) {
+        const int64_t i = (int64_t)b * KS + k;
+        if (status[i]) {
+            const int64_t o = (int64_t)b * KS + pos;
+            good_old[2 * o] = feat[2 * i]; good_old[2 * o + 1] = feat[2 * i + 1];
+            good_new[2 * o] = klt_next[2 * i]; good_new[2 * o + 1] = klt_next[2 * i + 1];
+            good_idx[o] = k;
+            pos++;
+        }
+    }
+    if (t == 0) good_n[b] = total;
+}
+
+__global__ void fill_mask_kernel(uint8_t *mask, const int32_t *good_n, int32_t *cq_n, int32_t *cq_flags)
+{
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < KS; k += blockDim.x) mask[(int64_t)b * KS + k] = 1;
+    if (threadIdx.x == 0) { cq_n[b] = good_n[b]; cq_flags[b] = 1; }
+}
+
+// G2: inlier compaction (Tracker.py:93-104), keyframe pruning (Mapping.py:118-125), Kabsch inputs,
+//     p_w (Mapping.py:97-116), centered_new (RawROAMSystem.py:198-199), next feature set (:296)
+__global__ __launch_bounds__(256) void g2_inliers_kernel(const float *__restrict__ good_old, const float *__restrict__ good_new,
+                                                         const int32_t *__restrict__ good_idx, const int32_t *__restrict__ good_n,
+                                                         const uint8_t *__restrict__ mask, const double *__restrict__ kf_pose,
+                                                         const double *__restrict__ kf_und, double *__restrict__ kf_und_tmp,
+                                                         double *__restrict__ kab_src, double *__restrict__ kab_tgt,
+                                                         double *__restrict__ p_w, double *__restrict__ p_jt,
+                                                         float *__restrict__ feat, int32_t *__restrict__ in_n)
+{
+    __shared__ int sh[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int G = good_n[b];
+    const int items = (KS + 255) / 256;
+    const int lo = t * items, hi = min(lo + items, G);
+    int c = 0;
+    for (int g = lo; g < hi; g++) c += mask[(int64_t)b * KS + g] ? 1 : 0;
+    int total;
+    int pos = blk_excl_scan(c, sh, &total);
+    const double kx = kf_pose[3 * b], ky = kf_pose[3 * b + 1], kth = kf_pose[3 * b + 2];
+    const double ck = cos(kth), sk = sin(kth);
+    for (int g = lo; g < hi; g++) {
+        const int64_t i = (int64_t)b * KS + g;
+        if (!mask[i]) continue;
+        const int64_t o = (int64_t)b * KS + pos;
+        const float ox = good_old[2 * i], oy = good_old[2 * i + 1];
+        const float nx = good_new[2 * i], ny = good_new[2 * i + 1];
+        kab_src[2 * o] = (double)ox; kab_src[2 * o + 1] = (double)oy;
+        kab_tgt[2 * o] = (double)nx; kab_tgt[2 * o + 1] = (double)ny;
+        const int64_t ki = (int64_t)b * KS + good_idx[i];
+        const double ux = kf_und[2 * ki], uy = kf_und[2 * ki + 1];
+        kf_und_tmp[2 * o] = ux; kf_und_tmp[2 * o + 1] = uy;
+        p_w[2 * o] = ck * ux - sk * uy + kx;
+        p_w[2 * o + 1] = sk * ux + ck * uy + ky;
+        p_jt[2 * o] = ((double)nx - CART_CENTER) * M_PER_PX;
+        p_jt[2 * o + 1] = ((double)ny - CART_CENTER) * M_PER_PX;
+        pos++;
+    }
+    __syncthreads();
+    // blobCoord = good_new.copy(): write after every read of good_* (distinct buffers, so no hazard)
+    pos -= c;
+    for (int g = lo; g < hi; g++) {
+        const int64_t i = (int64_t)b * KS + g;
+        if (!mask[i]) continue;
+        const int64_t o = (int64_t)b * KS + pos;
+        feat[2 * o] = good_new[2 * i]; feat[2 * o + 1] = good_new[2 * i + 1];
+        pos++;
+    }
+    if (t == 0) in_n[b] = total;
+}
+
+// G3: h *= 0.0864 (Tracker.py:124-125); T_wj = prev_pose @ [[R,h],[0,0,1]] (RawROAMSystem.py:201)
+__global__ void g3_init_transform_kernel(const double *__restrict__ kab_out, const double *__restrict__ pose,
+                                         double *__restrict__ T_wj0, double *__restrict__ T_init, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double *k = kab_out + 6 * (int64_t)b;
+    const double x = pose[3 * b], y = pose[3 * b + 1], th = pose[3 * b + 2];
+    const double c = cos(th), s = sin(th);
+    double *T0 = T_wj0 + 9 * (int64_t)b, *Ti = T_init + 9 * (int64_t)b;
+    T0[0] = c; T0[1] = -s; T0[2] = x; T0[3] = s; T0[4] = c; T0[5] = y; T0[6] = 0; T0[7] = 0; T0[8] = 1;
+    const double hx = k[4] * M_PER_PX, hy = k[5] * M_PER_PX;
+    Ti[0] = c * k[0] - s * k[2]; Ti[1] = c * k[1] - s * k[3]; Ti[2] = c * hx - s * hy + x;
+    Ti[3] = s * k[0] + c * k[2]; Ti[4] = s * k[1] + c * k[3]; Ti[5] = s * hx + c * hy + y;
+    Ti[6] = 0; Ti[7] = 0; Ti[8] = 1;
+}
+
+// G4: pose / velocity update, keyframe criteria (Mapping.py:149-174, RawROAMSystem.py:250-271),
+//     possible_kf.updateInfo undistortion (Mapping.py:65), result record
+__global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, const double *__restrict__ lm_out,
+                                                        const int32_t *__restrict__ lm_nfev, const int32_t *__restrict__ lm_info,
+                                                        const double *__restrict__ kab_out, double *__restrict__ pose,
+                                                        double *__restrict__ vel, double *__restrict__ kf_pose,
+                                                        double *__restrict__ kf_und, const double *__restrict__ kf_und_tmp,
+                                                        const double *__restrict__ p_jt, const int32_t *__restrict__ in_n,
+                                                        const int32_t *__restrict__ good_n, int32_t *__restrict__ feat_n,
+                                                        const int32_t *__restrict__ peaks_n, const int32_t *__restrict__ cq_flags,
+                                                        roam_lane_result *__restrict__ res)
+{
+    __shared__ double np_[3], nv_[3];
+    __shared__ int newkf;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int n = in_n[b];
+    if (t == 0) {
+        double px = pose[3 * b], py = pose[3 * b + 1], pth = pose[3 * b + 2];
+        double v0 = 0, v1 = 0, v2 = 0;
+        const double *k = kab_out + 6 * (int64_t)b;
+        if (n >= 2) {
+            if (cfg.motion_distortion) {
+                const double *s = lm_out + 6 * (int64_t)b;
+                v0 = s[0]; v1 = s[1]; v2 = s[2]; px = s[3]; py = s[4]; pth = s[5];
+            } else {
+                // updateTrajectory: convertRandHtoDeltas + appendRelativeDeltas (utils.py:99-103, trajectoryPlotting.py:28-35)
+                const double dx = k[4] * M_PER_PX, dy = k[5] * M_PER_PX, dth = atan2(k[2], k[0]);
+                const double c = cos(pth), s = sin(pth);
+                px += dx * c - dy * s; py += dx * s + dy * c; pth += dth;
+            }
+        }
+        np_[0] = px; np_[1] = py; np_[2] = pth; nv_[0] = v0; nv_[1] = v1; nv_[2] = v2;
+        const int retrack = n <= N_RETRACK;
+        const double dth = fabs(kf_pose[3 * b + 2] - pth);
+        const double ddx = kf_pose[3 * b] - px, ddy = kf_pose[3 * b + 1] - py;
+        const int good = (dth >= ROT_THR) || (ddx * ddx + ddy * ddy >= TRANS_THR_SQ);
+        newkf = retrack || good;
+        roam_lane_result *r = res + b;
+        r->pose[0] = px; r->pose[1] = py; r->pose[2] = pth;
+        r->velocity[0] = v0; r->velocity[1] = v1; r->velocity[2] = v2;
+        r->kabsch_R[0] = k[0]; r->kabsch_R[1] = k[1]; r->kabsch_R[2] = k[2]; r->kabsch_R[3] = k[3];
+        r->kabsch_h[0] = k[4] * M_PER_PX; r->kabsch_h[1] = k[5] * M_PER_PX;
+        r->n_tracked = feat_n[b]; r->n_good = good_n[b]; r->n_inliers = n; r->n_peaks = peaks_n[b];
+        r->lm_nfev = (n >= 2 && cfg.motion_distortion) ? lm_nfev[b] : 0;
+        r->lm_info = (n >= 2 && cfg.motion_distortion) ? lm_info[b] : 0;
+        r->flags = (cq_flags[b] & 1) | (newkf ? 2 : 0) | (retrack ? 4 : 0);
+        r->pad = 0;
+    }
+    __syncthreads();
+    const double v0 = nv_[0], v1 = nv_[1], v2 = nv_[2];
+    for (int j = t; j < n; j += 256) {
+        const int64_t o = (int64_t)b * KS + j;
+        if (newkf) {
+            const double x = p_jt[2 * o], y = p_jt[2 * o + 1];
+            const double dT = 0.25 * atan2(-y, -x) / TWO_PI;
+            const double a = v2 * dT, ca = cos(a), sa = sin(a);
+            kf_und[2 * o] = ca * x - sa * y + v0 * dT;
+            kf_und[2 * o + 1] = sa * x + ca * y + v1 * dT;
+        } else {
+            kf_und[2 * o] = kf_und_tmp[2 * o]; kf_und[2 * o + 1] = kf_und_tmp[2 * o + 1];
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        pose[3 * b] = np_[0]; pose[3 * b + 1] = np_[1]; pose[3 * b + 2] = np_[2];
+        vel[3 * b] = v0; vel[3 * b + 1] = v1; vel[3 * b + 2] = v2;
+        if (newkf) { kf_pose[3 * b] = np_[0]; kf_pose[3 * b + 1] = np_[1]; kf_pose[3 * b + 2] = np_[2]; }
+        feat_n[b] = n;
+    }
+}
+
+// features -> keyframe locals: undistort(velocity, (pts - center) * m/px) (Mapping.py:59-66)
+__global__ void lane_kf_reset_kernel(const float *__restrict__ feat, int K, const double *__restrict__ vel,
+                                     double *__restrict__ kf_und)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= K) return;
+    const double x = ((double)feat[2 * j] - CART_CENTER) * M_PER_PX, y = ((double)feat[2 * j + 1] - CART_CENTER) * M_PER_PX;
+    const double dT = 0.25 * atan2(-y, -x) / TWO_PI;
+    const double a = vel[2] * dT, ca = cos(a), sa = sin(a);
+    kf_und[2 * j] = ca * x - sa * y + vel[0] * dT;
+    kf_und[2 * j + 1] = sa * x + ca * y + vel[1] * dT;
+}
+
+// ------------------------------------------------------------------------------ API
+extern "C" {
+
+int32_t roam_engine_destroy(roam_ctx *ctx)
+{
+    if (!ctx) return ROAM_E_ARG;
+    Engine *e = ctx->engine;
+    if (!e) return ROAM_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (void *p : e->allocs) hipFree(p);
+    if (e->ev_ok) for (auto &ev : e->ev) hipEventDestroy(ev);
+    delete e;
+    ctx->engine = nullptr;
+    return ROAM_OK;
+}
+
+int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
+{
+    if (!ctx) return ROAM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ARG_CHECK(ctx, cfg && cfg->lanes >= 1 && cfg->rows >= 1 && cfg->clip >= 32 && cfg->clip <= ROAM_MAX_COLS &&
+                       cfg->payload_off >= 0 && cfg->stride >= cfg->payload_off + cfg->clip && cfg->pool_scans >= 1 &&
+                       cfg->peaks_cap >= 1);
+    roam_engine_destroy(ctx);
+    Engine *e = new (std::nothrow) Engine();
+    if (!e) return ROAM_E_HIP;
+    ctx->engine = e;
+    e->cfg = *cfg;
+    const int B = e->B = cfg->lanes;
+    e->W = 2 * (cfg->clip / 2);
+    e->stage_cap = (cfg->clip + 1) / 2;
+    pyr_desc_init(&e->pd, e->W, e->W);
+    e->rec_bytes = (size_t)cfg->rows * cfg->stride;
+    const int nw = KS / 64;
+    bool ok = true;
+    ok = ok && dalloc(ctx, e, &e->pool, e->rec_bytes * cfg->pool_scans);
+    ok = ok && dalloc(ctx, e, &e->pyr[0], (size_t)e->pd.lane_stride * B);
+    ok = ok && dalloc(ctx, e, &e->pyr[1], (size_t)e->pd.lane_stride * B);
+    ok = ok && dalloc(ctx, e, &e->row_stage, (size_t)B * cfg->rows * e->stage_cap);
+    ok = ok && dalloc(ctx, e, &e->row_count, (size_t)B * cfg->rows);
+    ok = ok && dalloc(ctx, e, &e->peaks_out, (size_t)B * cfg->peaks_cap * 2);
+    ok = ok && dalloc(ctx, e, &e->peaks_n, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->scan_idx, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->feat, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->feat_n, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->klt_next, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->klt_err, (size_t)B * KS);
+    ok = ok && dalloc(ctx, e, &e->klt_status, (size_t)B * KS);
+    ok = ok && dalloc(ctx, e, &e->good_old, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->good_new, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->good_idx, (size_t)B * KS);
+    ok = ok && dalloc(ctx, e, &e->good_n, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->adj, (size_t)B * KS * nw);
+    ok = ok && dalloc(ctx, e, &e->cq_stack, (size_t)B * (KS + 2) * nw);
+    ok = ok && dalloc(ctx, e, &e->cq_mask, (size_t)B * KS);
+    ok = ok && dalloc(ctx, e, &e->cq_n, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->cq_flags, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->kab_src, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->kab_tgt, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->kab_out, (size_t)B * 6);
+    ok = ok && dalloc(ctx, e, &e->in_n, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->kf_pose, (size_t)B * 3);
+    ok = ok && dalloc(ctx, e, &e->kf_und, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->kf_und_tmp, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->pose, (size_t)B * 3);
+    ok = ok && dalloc(ctx, e, &e->vel, (size_t)B * 3);
+    ok = ok && dalloc(ctx, e, &e->T_wj0, (size_t)B * 9);
+    ok = ok && dalloc(ctx, e, &e->T_init, (size_t)B * 9);
+    ok = ok && dalloc(ctx, e, &e->p_w, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->p_jt, (size_t)B * KS * 2);
+    ok = ok && dalloc(ctx, e, &e->lm_work, (size_t)B * ((size_t)(2 * KS + 3) * 9 + KS));
+    ok = ok && dalloc(ctx, e, &e->lm_out, (size_t)B * 6);
+    ok = ok && dalloc(ctx, e, &e->lm_nfev, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->lm_info, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->results, (size_t)B);
+    if (!ok) { roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    for (auto &ev : e->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    }
+    e->ev_ok = true;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
+#define ENGINE()                                  \
+    if (!ctx) return ROAM_E_ARG;                  \
+    Engine *e = ctx->engine;                      \
+    if (!e) { ROAM_SET_ERR(ctx, "engine not created"); return ROAM_E_STATE; } \
+    HIP_TRY(ctx, hipSetDevice(ctx->device))
+
+int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *rec)
+{
+    ENGINE();
+    ARG_CHECK(ctx, rec && pool_idx >= 0 && pool_idx < e->cfg.pool_scans);
+    HIP_TRY(ctx, hipMemcpyAsync(e->pool + (size_t)pool_idx * e->rec_bytes, rec, e->rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
+static WarpSrc pool_warp_src(Engine *e, const int32_t *lane_index)
+{
+    WarpSrc s = {e->pool, (int64_t)e->rec_bytes, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, lane_index};
+    return s;
+}
+
+int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, int32_t K)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && K >= 0 && K <= KS && (K == 0 || pts));
+    float *f = e->feat + (size_t)lane * KS * 2;
+    if (K > 0) HIP_TRY(ctx, hipMemcpyAsync(f, pts, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(e->feat_n + lane, &K, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    // the frame that triggers a retrack also adds a keyframe at the latest pose (RawROAMSystem.py:250-270):
+    // kf pose = latest pose, kf locals = undistort(velocity, centred features)
+    HIP_TRY(ctx, hipMemcpyAsync(e->kf_pose + 3 * (size_t)lane, e->pose + 3 * (size_t)lane, sizeof(double) * 3,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    if (K > 0) {
+        hipLaunchKernelGGL(lane_kf_reset_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, f, K,
+                           e->vel + 3 * (size_t)lane, e->kf_und + (size_t)lane * KS * 2);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
+int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const float *pts, int32_t K,
+                              const double *pose3)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && pool_idx >= 0 && pool_idx < e->cfg.pool_scans && pose3 && K >= 0 && K <= KS);
+    // previous-image pyramid of this lane from the pool scan
+    uint8_t *pyr = e->pyr[e->cur] + (size_t)lane * e->pd.lane_stride;
+    WarpSrc ws = {e->pool + (size_t)pool_idx * e->rec_bytes, 0, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, nullptr};
+    HIP_TRY(ctx, launch_polar_to_cart(ctx->stream, ws, 1, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride, nullptr, 0));
+    HIP_TRY(ctx, launch_build_pyramid(ctx->stream, pyr, e->pd, 1));
+    double zero[3] = {0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane, pose3, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(e->vel + 3 * (size_t)lane, zero, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return roam_engine_set_features(ctx, lane, pts, K);
+}
+
+int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
+{
+    ENGINE();
+    ARG_CHECK(ctx, scan_idx);
+    const int B = e->B;
+    for (int b = 0; b < B; b++) ARG_CHECK(ctx, scan_idx[b] >= 0 && scan_idx[b] < e->cfg.pool_scans);
+    hipStream_t st = ctx->stream;
+    const roam_engine_cfg &c = e->cfg;
+    const int nw = KS / 64;
+    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx, scan_idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, st));
+    uint8_t *prev = e->pyr[e->cur], *next = e->pyr[e->cur ^ 1];
+
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], st));
+    PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};
+    HIP_TRY(ctx, launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], st));
+    HIP_TRY(ctx, launch_polar_to_cart(st, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride, nullptr, 0));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], st));
+    HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
+    HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KS, KS, B, e->klt_next, e->klt_status, e->klt_err));
+    hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,
+                       e->good_old, e->good_new, e->good_idx, e->good_n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_GRAPH], st));
+    if (c.reject_outliers) {
+        HIP_TRY(ctx, launch_consistency_graph(st, e->good_old, e->good_new, e->good_n, KS, KS, B, 0.5 / M_PER_PX, e->adj, nw));
+        HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
+        HIP_TRY(ctx, launch_max_clique(st, e->adj, e->good_n, KS, KS, nw, B, c.clique_node_limit, e->cq_stack, e->cq_mask, e->cq_n, e->cq_flags));
+    } else {
+        HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
+        hipLaunchKernelGGL(fill_mask_kernel, dim3(B), dim3(256), 0, st, e->cq_mask, e->good_n, e->cq_n, e->cq_flags);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_KABSCH], st));
+    hipLaunchKernelGGL(g2_inliers_kernel, dim3(B), dim3(256), 0, st, e->good_old, e->good_new, e->good_idx, e->good_n, e->cq_mask,
+                       e->kf_pose, e->kf_und, e->kf_und_tmp, e->kab_src, e->kab_tgt, e->p_w, e->p_jt, e->feat, e->in_n);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, launch_kabsch(st, e->kab_src, e->kab_tgt, e->in_n, KS, KS, B, e->kab_out));
+    hipLaunchKernelGGL(g3_init_transform_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->kab_out, e->pose, e->T_wj0, e->T_init, B);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_LM], st));
+    if (c.motion_distortion) {
+        MdsProblemDesc P;
+        P.T_wj0 = e->T_wj0; P.T_init = e->T_init; P.p_w = e->p_w; P.p_jt = e->p_jt; P.count = e->in_n;
+        P.N = KS; P.nstride = KS; P.B = B; P.period = 0.25;
+        for (int i = 0; i < 5; i++) P.sigma5[i] = c.sigma5[i];
+        HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
+    }
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));
+    hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
+                       e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n,
+                       e->cq_flags, e->results);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
+    e->cur ^= 1;
+    e->stepped = true;
+    return ROAM_OK;
+}
+
+int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n)
+{
+    ENGINE();
+    ARG_CHECK(ctx, out && n >= 1 && n <= e->B);
+    HIP_TRY(ctx, hipMemcpyAsync(out, e->results, sizeof(roam_lane_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
+int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t lane, float *pts, int32_t cap, int32_t *K)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && pts && K && cap >= 0);
+    int32_t n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, e->feat_n + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *K = n;
+    const int m = n < cap ? n : cap;
+    if (m > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(pts, e->feat + (size_t)lane * KS * 2, sizeof(float) * 2 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return n > cap ? ROAM_E_CAPACITY : ROAM_OK;
+}
+
+int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_t cap, int64_t *n_out)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && out && n_out && cap >= 0);
+    int32_t n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, e->peaks_n + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    int64_t m = n < cap ? n : cap;
+    if (m > e->cfg.peaks_cap) m = e->cfg.peaks_cap;
+    if (m > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, e->peaks_out + (size_t)lane * e->cfg.peaks_cap * 2, sizeof(int32_t) * 2 * (size_t)m,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return (n > cap || n > e->cfg.peaks_cap) ? ROAM_E_CAPACITY : ROAM_OK;
+}
+
+int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap, int32_t *n)
+{
+    ENGINE();
+    ARG_CHECK(ctx, ms_out && n && cap >= ST_COUNT);
+    if (!e->stepped) { ROAM_SET_ERR(ctx, "no step recorded"); return ROAM_E_STATE; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ST_COUNT; i++) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        ms_out[i] = ms;
+        if (names_out) names_out[i] = kStageNames[i];
+    }
+    *n = ST_COUNT;
+    return ROAM_OK;
+}
+
+// re-launch one streaming kernel of the step `reps` times over all lanes (inputs resident, outputs
+// overwritten in the scratch "next" pyramid / peak buffers) and time it with HIP events on the
+// context stream.  algo_bytes = algorithmic HBM bytes per launch.
+int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms, double *algo_bytes)
+{
+    ENGINE();
+    ARG_CHECK(ctx, name && reps >= 1 && avg_ms);
+    if (!e->stepped) { ROAM_SET_ERR(ctx, "run a step first"); return ROAM_E_STATE; }
+    hipStream_t st = ctx->stream;
+    const roam_engine_cfg &c = e->cfg;
+    const int B = e->B;
+    uint8_t *next = e->pyr[e->cur ^ 1];       // not the live "previous" pyramid
+    double bytes = 0;
+    hipEvent_t a, b;
+    HIP_TRY(ctx, hipEventCreate(&a));
+    HIP_TRY(ctx, hipEventCreate(&b));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipEventRecord(a, st));
+    for (int r = 0; r < reps; r++) {
+        if (!strcmp(name, "warp_quantise")) {
+            HIP_TRY(ctx, launch_polar_to_cart(st, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride, nullptr, 0));
+            bytes = (double)B * ((double)c.rows * c.clip + (double)e->W * e->W);
+        } else if (!strcmp(name, "ingest_peaks")) {
+            PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};
+            hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n);
+            HIP_TRY(ctx, er);
+            bytes = (double)B * ((double)c.rows * c.clip);
+        } else if (!strcmp(name, "pyramid")) {
+            HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
+            double rd = 0, wr = 0;
+            for (int l = 0; l + 1 < ROAM_PYR_LEVELS; l++) { rd += (double)e->pd.w[l] * e->pd.h[l]; wr += (double)e->pd.w[l + 1] * e->pd.h[l + 1]; }
+            bytes = (double)B * (rd + wr);
+        } else {
+            hipEventDestroy(a); hipEventDestroy(b);
+            ROAM_SET_ERR(ctx, "unknown kernel '%s'", name);
+            return ROAM_E_ARG;
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(b, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    *avg_ms = ms / reps;
+    if (algo_bytes) *algo_bytes = bytes;
+    return ROAM_OK;
+}
+
+int32_t roam_doh_blobs(roam_ctx *ctx, const float *, int32_t, int32_t, double, double, int32_t, double, double, double *, int32_t, int32_t *)
+{
+    if (!ctx) return ROAM_E_ARG;
+    ROAM_SET_ERR(ctx, "doh not built yet");
+    return ROAM_E_STATE;
+}
+
+}  // extern "C"

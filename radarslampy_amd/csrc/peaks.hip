@@ -190,7 +190,7 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
     }
     __syncthreads();
     const float var = __fdiv_rn(block_np_sum(&pw, sq, M), fM);
-    const float thr = __fadd_rn(mean, __fsqrt_rn(var));
+    const float thr = __fadd_rn(mean, rn_sqrtf(var));
 
     // ---- threshold + ordered compaction
     const int kitems = (M + PK_T - 1) / PK_T;

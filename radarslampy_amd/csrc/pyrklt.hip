@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
         const float dA = __fsub_rn(A11, A22);
         const float minEig = __fdiv_rn(
             __fsub_rn(__fadd_rn(A22, A11),
-                      __fsqrt_rn(__fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
+                      rn_sqrtf(__fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
             (float)(2 * KW * KW));
         if (minEig < min_eig_thr || D < 1.1920929e-07f) {
             if (level == 0) st = 0;

@@ -7,6 +7,14 @@
 #include <vector>
 #include "../../include/roam_abi.h"
 
+// HIP's __fsqrt_rn maps to the APPROXIMATE v_sqrt_f32 (ocml native sqrt) unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined; __builtin_sqrtf lowers to the correctly
+// rounded expansion (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  The other
+// __f*_rn intrinsics are plain operators, so every translation unit is compiled with
+// -ffp-contract=off (and says so with the pragma below) to keep a*b+c un-fused.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float rn_sqrtf(float x) { return __builtin_sqrtf(x); }
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;

@@ -65,7 +65,7 @@ __device__ __forceinline__ float warp_pixel(const void *base, int64_t row_stride
 {
     const float fx = __fsub_rn((float)x, (float)R);
     const float fy = __fsub_rn((float)y, (float)R);
-    const float mag = __fsqrt_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)));
+    const float mag = rn_sqrtf(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)));
     const float ang = __fmul_rn(fast_atan2_deg(fy, fx), (float)(3.14159265358979323846 / 180.0));
     const double rho = __ddiv_rn((double)mag, Kmag);
     const double phi = __ddiv_rn((double)ang, Kangle);
