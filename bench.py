@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""bench.py — scan-pairs/s of the MI355X-native radar-odometry front end.
+
+One "step" = every resident lane (independent sequence) advances by ONE scan pair through the
+whole hot path (ingest+peaks -> warp+quantise -> pyramid -> KLT -> outlier rejection ->
+Kabsch -> motion-distortion LM -> keyframe bookkeeping), inputs already resident in HBM.
+value = lanes * steps * n_gpus / max-over-ranks wall time.  Multi-GPU = one process per GPU,
+sequences sharded by rank, no data-path collective ("weak" scaling).
+
+Prints ONE JSON line (rank 0) with the `roofline` and `cpu_baseline` objects described in
+DESIGN.md.  The cpu_baseline leg times the oracle (CPU restatement, 1 core) on a bounded
+sample of the same synthetic workload - it is a reported baseline, not the optimisation target."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=64, help="independent sequences resident per GPU")
+    ap.add_argument("--frames", type=int, default=7, help="frames per synthetic sequence (played ping-pong)")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences generated per rank")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="scan pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
+    ap.add_argument("--kernel-reps", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+
+    ctx = _ffi.Context(local_rank)
+    info = ctx.device_info()
+    B, T, D = args.lanes, args.frames, max(1, min(args.distinct, args.lanes))
+    seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, n_movers=16, distortion=not args.no_md) for d in range(D)]
+    eng = Engine(B, D * T, ctx=ctx, motion_distortion=not args.no_md)
+    for d, (recs, poses, feat) in enumerate(seqs):
+        for t in range(T):
+            eng.upload_scan(d * T + t, recs[t])
+    for b in range(B):
+        d = b % D
+        eng.init_lane(b, d * T, seqs[d][2], seqs[d][1][0])
+
+    # ping-pong frame schedule 1,2,..,T-1,T-2,..,0,1,..
+    cyc = list(range(1, T)) + list(range(T - 2, -1, -1))
+
+    def idx(step):
+        t = cyc[step % len(cyc)]
+        return np.array([(b % D) * T + t for b in range(B)], np.int32)
+
+    def barrier():
+        eng.synchronize()
+        if dist is not None:
+            dist.barrier()
+            eng.synchronize()
+
+    s = 0
+    for _ in range(args.warmup):
+        eng.step(idx(s)); s += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(idx(s)); s += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    res = eng.results()
+    stages = eng.stage_times()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    out = None
+    if rank == 0:
+        pairs = B * args.steps * world
+        value = pairs / dt
+        # ---- roofline of the dominant kernel (HIP events on the kernel's own stream)
+        streaming = {k: stages[k] for k in ("ingest_peaks", "warp_quantise", "pyramid")}
+        dom_stage = max(stages, key=stages.get)
+        dom_stream = max(streaming, key=streaming.get)
+        ms, algo_bytes = eng.time_kernel(dom_stream, args.kernel_reps)
+        achieved = algo_bytes / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom_stream, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                    "dominant_stage_of_step": dom_stage}
+        # whole-path view: SURVEY 8d B_min = 13.07 MB per steady pair
+        path_gbs = 13.07e6 * (value / world) / 1e9
+        cpu = None
+        if args.cpu_pairs > 0:
+            import oracle
+            recs, poses, feat = seqs[0]
+            P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=not args.no_md)
+            n = 0
+            c0 = time.perf_counter()
+            while n < args.cpu_pairs:
+                P.step(recs[cyc[n % len(cyc)]]); n += 1
+            cdt = time.perf_counter() - c0
+            cpu = {"value": round(n / cdt, 3), "unit": "scan-pairs/s", "cores": 1, "kind": "port",
+                   "sample": f"{n} consecutive scan pairs of synthetic sequence 0 (same workload, oracle C/numpy restatement, 1 thread)"}
+        out = {
+            "metric": "radar scan-pairs/sec (400x3768 polar)", "value": round(value, 2), "unit": "scan-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
+            "data": f"synthetic Oxford-format 400x3779 u8 records; {D} distinct seeded sequences x {T} frames per rank replicated over {B} lanes, ping-pong replay",
+            "config": {"workload": "steady-state scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
+                                   + ("motion-distortion LM" if not args.no_md else "dead reckoning") + ")",
+                       "lanes_per_gpu": B, "frames": T, "device": info["name"], "arch": info["arch"],
+                       "mean_tracked": round(float(np.mean([r["n_tracked"] for r in res])), 1),
+                       "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
+                       "stage_ms_last_step": {k: round(v, 4) for k, v in stages.items()},
+                       "whole_path_Bmin_GBs_per_gpu": round(path_gbs, 3)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    eng.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

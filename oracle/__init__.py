@@ -374,3 +374,113 @@ def track_glue(klt_out, do_reject=True):
         corrStatus = corrStatus.copy()
         corrStatus[rng[corrStatus.flatten().astype(bool)]] &= mask[:, np.newaxis]
     return good_old, good_new, 0.0, corrStatus
+
+
+# ------------------------------------------------------------------ a15: the per-scan loop body
+RADAR_CART_CENTER = np.array([1012, 1012])   # RawROAMSystem.py:16
+N_FEATURES_BEFORE_RETRACK = 60               # getFeatures.py:57 (import-time binding, RawROAMSystem.py:7)
+ROT_THRESHOLD = 0.2                          # Mapping.py:13
+TRANS_THRESHOLD_SQ = 4.0                     # Mapping.py:14-15
+
+
+class Keyframe:
+    """Mapping.Keyframe (Mapping.py:21-125), fields the loop uses."""
+
+    def __init__(self, pose, featurePointsLocal, record_u8, velocity, with_peaks=True):
+        self.updateInfo(pose, featurePointsLocal, record_u8, velocity, with_peaks)
+
+    def updateInfo(self, pose, featurePointsLocal, record_u8, velocity, with_peaks=True):
+        self.pose = np.asarray(pose, np.float64)
+        self.featurePointsLocal = featurePointsLocal
+        if with_peaks and record_u8 is not None:
+            self.pointCloud = peaks_from_record_u8(record_u8)               # Mapping.py:62
+        self.velocity = velocity
+        self.prunedUndistortedLocals = MotionDistortionSolver.undistort(velocity, featurePointsLocal)[:, :2]
+
+    def pruneFeaturePoints(self, corrStatus):
+        self.prunedUndistortedLocals = self.prunedUndistortedLocals[corrStatus.flatten().astype(bool)]
+
+    def getPrunedFeaturesGlobalPosition(self):
+        x, y, th = self.pose
+        c, s = np.cos(th), np.sin(th)
+        R = np.array([[c, -s], [s, c]])
+        return (R @ self.prunedUndistortedLocals.T + np.array([[x], [y]])).T
+
+
+class OdometryPipeline:
+    """CPU restatement of the body of RawROAMSystem.run (RawROAMSystem.py:139-298) without
+    plotting: one call to step() = one scan pair.  Feature (re)detection is injected
+    (`detect(cart_f32) -> (k,2) [x,y]`) because blob_doh is a separate, unpinned stage."""
+
+    def __init__(self, first_record_u8, init_features_xy, init_pose, reject_outliers=True,
+                 motion_distortion=True, detect=None, payload_off=11, clip=MAX_RANGE_CLIP_PX):
+        self.off, self.clip = payload_off, clip
+        self.reject, self.md, self.detect = reject_outliers, motion_distortion, detect
+        self.MDS = MotionDistortionSolver(np.diag([4, 4]), np.diag([1, 1, (5 * np.pi / 180) ** 2]))
+        self.prev_pose = convertPoseToTransform(init_pose)
+        self.pose = np.asarray(init_pose, np.float64)
+        self.prevCart8 = self._cart_u8(first_record_u8)
+        self.prevPyr = build_pyramid(self.prevCart8, 3)
+        self.blobCoord = np.ascontiguousarray(init_features_xy, np.float32)
+        metric = (self.blobCoord - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
+        self.old_kf = Keyframe(self.pose, metric, first_record_u8, np.zeros(3))
+        self.last = {}
+
+    def _cart_u8(self, rec):
+        polar = rec[:, self.off:self.off + self.clip].astype(np.float32) / 255.
+        return convertPolarImageToCartesian(polar, want_u8=True)[1]
+
+    def step(self, rec_u8):
+        cur8 = self._cart_u8(rec_u8)
+        curPyr = build_pyramid(cur8, 3)
+        pts = self.blobCoord
+        nxt, status, err = klt_on_pyramids(self.prevPyr, curPyr, pts)
+        status &= (err < ERR_THRESHOLD)
+        good = (status == 1).flatten()
+        klt_out = (nxt[good], pts[good], nxt[~good], pts[~good], status)
+        n_good = int(good.sum())
+        if self.reject:
+            good_old, good_new, _, corrStatus = track_glue(klt_out, True)
+        else:
+            good_old, good_new, corrStatus = pts[good], nxt[good], status
+        self.old_kf.pruneFeaturePoints(corrStatus)
+        n = good_new.shape[0]
+        peaks = peaks_from_record_u8(rec_u8, self.off, self.clip)
+        out = dict(n_tracked=len(pts), n_good=n_good, n_inliers=n, n_peaks=len(peaks))
+        if n >= 2:
+            R, h = calculateTransformSVD(good_old, good_new)
+            h = h * RANGE_RESOLUTION_CART_M
+            centered_new = (good_new - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
+            if self.md:
+                p_w = self.old_kf.getPrunedFeaturesGlobalPosition()
+                T_wj = self.prev_pose @ np.block([[R, h], [np.zeros((2,)), 1]])
+                self.MDS.update_problem(self.prev_pose, p_w, centered_new, T_wj)
+                sol = self.MDS.optimize_library()
+                pose, velocity = sol[3:], sol[:3]
+            else:
+                x, y, th = self.pose
+                dx, dy, dth = h[0, 0], h[1, 0], np.arctan2(R[1, 0], R[0, 0])
+                pose = np.array([x + dx * np.cos(th) - dy * np.sin(th), y + dx * np.sin(th) + dy * np.cos(th), th + dth])
+                velocity = np.zeros(3)
+            out.update(R=R, h=h)
+        else:
+            pose, velocity = self.pose, np.zeros(3)
+            centered_new = (good_new - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
+        retrack = n <= N_FEATURES_BEFORE_RETRACK
+        dth = abs(self.old_kf.pose[2] - pose[2])
+        dtr = ((self.old_kf.pose[:2] - pose[:2]) ** 2).sum()
+        newkf = retrack or dth >= ROT_THRESHOLD or dtr >= TRANS_THRESHOLD_SQ
+        if newkf:
+            if retrack and self.detect is not None:
+                cart_f32 = convertPolarImageToCartesian(rec_u8[:, self.off:self.off + self.clip].astype(np.float32) / 255.)
+                good_new = append_dedupe(good_new, self.detect(cart_f32))
+                centered_new = (good_new - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
+            self.old_kf = Keyframe(pose, centered_new, None, velocity, with_peaks=False)
+        out.update(pose=np.asarray(pose, np.float64), velocity=np.asarray(velocity, np.float64), new_keyframe=newkf,
+                   retrack=retrack, peaks=peaks)
+        self.blobCoord = np.ascontiguousarray(good_new, np.float32)
+        self.prevCart8, self.prevPyr = cur8, curPyr
+        self.pose = np.asarray(pose, np.float64)
+        self.prev_pose = convertPoseToTransform(self.pose)
+        self.last = out
+        return out

@@ -1,0 +1,91 @@
+"""Batched device-resident scan-pair engine (Python face of the roam_engine_* C-ABI).
+
+B independent sequences advance in lock-step: one `step()` = one scan pair per lane,
+everything between the raw u8 record in HBM and the SE(2) pose on the device.  This is the
+MI355X-first shape of RawROAMSystem.run's loop body (reference RawROAMSystem.py:162-298):
+the reference's single sequential loop becomes the batch dimension that fills 256 CUs."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class Engine:
+    def __init__(self, lanes: int, pool_scans: int, ctx: _ffi.Context = None, rows=400, stride=3779, payload_off=11,
+                 clip=2025, peaks_cap=65536, reject_outliers=True, motion_distortion=True, clique_node_limit=0,
+                 sigma5=(4.0, 4.0, 1.0, 1.0, (5 * np.pi / 180) ** 2)):
+        self.ctx = ctx or _ffi.default_context()
+        self.lib = self.ctx.lib
+        cfg = _ffi.EngineCfg(lanes, rows, stride, payload_off, clip, pool_scans, peaks_cap, int(reject_outliers),
+                             int(motion_distortion), int(clique_node_limit), (C.c_double * 5)(*sigma5))
+        self.cfg = cfg
+        self.lanes, self.pool_scans = lanes, pool_scans
+        self.rows, self.stride = rows, stride
+        self.ctx.check(self.lib.roam_engine_create(self.ctx.h, C.byref(cfg)))
+        self._res = (_ffi.LaneResult * lanes)()
+
+    def close(self):
+        if self.ctx is not None and getattr(self.ctx, "h", None):
+            self.lib.roam_engine_destroy(self.ctx.h)
+        self.ctx = None
+
+    def upload_scan(self, pool_idx: int, rec: np.ndarray):
+        rec = np.ascontiguousarray(rec, np.uint8)
+        assert rec.shape == (self.rows, self.stride), rec.shape
+        self.ctx.check(self.lib.roam_engine_upload_scan(self.ctx.h, int(pool_idx), _ffi._ptr(rec)))
+
+    def init_lane(self, lane: int, pool_idx: int, pts: np.ndarray, pose):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        pose = np.ascontiguousarray(pose, np.float64)
+        self.ctx.check(self.lib.roam_engine_init_lane(self.ctx.h, int(lane), int(pool_idx), _ffi._ptr(pts), pts.shape[0],
+                                                      _ffi._ptr(pose)))
+
+    def set_features(self, lane: int, pts: np.ndarray):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        self.ctx.check(self.lib.roam_engine_set_features(self.ctx.h, int(lane), _ffi._ptr(pts), pts.shape[0]))
+
+    def step(self, scan_idx):
+        idx = np.ascontiguousarray(scan_idx, np.int32)
+        assert idx.shape == (self.lanes,)
+        self.ctx.check(self.lib.roam_engine_step(self.ctx.h, _ffi._ptr(idx)))
+
+    def synchronize(self):
+        self.ctx.check(self.lib.roam_synchronize(self.ctx.h))
+
+    def results(self):
+        self.ctx.check(self.lib.roam_engine_results(self.ctx.h, self._res, self.lanes))
+        out = []
+        for r in self._res:
+            out.append(dict(pose=np.array(r.pose[:]), velocity=np.array(r.velocity[:]),
+                            R=np.array(r.kabsch_R[:]).reshape(2, 2), h=np.array(r.kabsch_h[:]).reshape(2, 1),
+                            n_tracked=r.n_tracked, n_good=r.n_good, n_inliers=r.n_inliers, n_peaks=r.n_peaks,
+                            lm_nfev=r.lm_nfev, lm_info=r.lm_info, clique_proven=bool(r.flags & 1),
+                            new_keyframe=bool(r.flags & 2), retrack=bool(r.flags & 4)))
+        return out
+
+    def lane_features(self, lane: int):
+        pts = np.empty((_ffi.MAX_FEATURES, 2), np.float32)
+        K = C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_lane_features(self.ctx.h, int(lane), _ffi._ptr(pts), _ffi.MAX_FEATURES, C.byref(K)))
+        return pts[:K.value].copy()
+
+    def lane_peaks(self, lane: int):
+        cap = self.cfg.peaks_cap
+        out = np.empty((cap, 2), np.int32)
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.roam_engine_lane_peaks(self.ctx.h, int(lane), _ffi._ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def stage_times(self):
+        ms = (C.c_float * 16)()
+        names = (C.c_char_p * 16)()
+        n = C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_stage_times(self.ctx.h, ms, names, 16, C.byref(n)))
+        return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+    def time_kernel(self, name: str, reps: int = 20):
+        ms = C.c_float(0)
+        by = C.c_double(0)
+        self.ctx.check(self.lib.roam_engine_time_kernel(self.ctx.h, name.encode(), int(reps), C.byref(ms), C.byref(by)))
+        return float(ms.value), float(by.value)

@@ -1,0 +1,122 @@
+"""Seeded synthetic Oxford-format radar sequences (host-side input generator).
+
+A record is what parseData.extractDataFromRadarImage (reference parseData.py:17-53) decodes:
+400 azimuth rows x (8 B int64 us timestamp | 2 B uint16 encoder | 1 B valid | 3768 B power).
+The world is a set of static point reflectors (+ optional movers) seen from an SE(2)
+trajectory; each reflector is rendered as a Gaussian blob in (azimuth, range) on top of
+range-correlated speckle whose statistics follow the real `data/tiny` scans (mean ~11/255).
+Conventions match the reference: Cartesian pixel = 1012 + metres/0.0864 with x right / y
+down, azimuth row = atan2(y, x) * 400 / 2pi, range bin = r / 0.0432 m, pose T_wj maps
+sensor-frame metres to world metres (RawROAMSystem.py:194-201), optional constant-velocity
+intra-scan distortion with the time offsets of motionDistortion.py:107-153.
+This is input data generation, not part of the measured path."""
+import numpy as np
+
+ROWS, NBINS, META = 400, 3768, 11
+STRIDE = META + NBINS
+RANGE_RES = 0.0432
+M_PER_PX = 0.0864
+CENTER = 1012.0
+CLIP = 2025
+
+
+def se2(x, y, th):
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c, -s, x], [s, c, y], [0, 0, 1.0]])
+
+
+class World:
+    def __init__(self, seed: int, n_static: int = 320, n_movers: int = 0, extent_m: float = 85.0):
+        rng = np.random.default_rng(seed)
+        self.static = rng.uniform(-extent_m, extent_m, size=(n_static, 2)) + rng.uniform(-5, 5, size=2)
+        self.amp = rng.uniform(70, 136, size=n_static + n_movers)
+        self.movers = rng.uniform(-extent_m * 0.6, extent_m * 0.6, size=(n_movers, 2))
+        self.mover_vel = rng.uniform(-6, 6, size=(n_movers, 2))       # m/s
+        self.seed = seed
+
+
+def trajectory(n_frames: int, seed: int, speed_m=(0.8, 1.6), yaw=(-0.03, 0.03), pose0=(0.0, 0.0, 0.0)):
+    """poses (n,3) [x,y,th] world; per-frame deltas like full_seq_1 (mean ~1 m/frame)."""
+    rng = np.random.default_rng(seed + 7919)
+    T = se2(*pose0)
+    poses = [np.array(pose0, float)]
+    for _ in range(n_frames - 1):
+        d = se2(rng.uniform(*speed_m), rng.uniform(-0.05, 0.05), rng.uniform(*yaw))
+        T = T @ d
+        poses.append(np.array([T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])]))
+    return np.array(poses)
+
+
+def _speckle(rng, rows, cols, mean=9.0):
+    from scipy.ndimage import uniform_filter1d
+    n = rng.exponential(mean, size=(rows, cols)).astype(np.float32)
+    n = uniform_filter1d(n, size=5, axis=1, mode="nearest")          # range-correlated like real scans
+    n = uniform_filter1d(n, size=2, axis=0, mode="wrap")
+    return n
+
+
+def render_record(world: World, pose, t_index: int = 0, velocity=None, seed: int = 0, timestamp_us: int = 1547131046353776):
+    """One 400 x 3779 u8 record of `world` seen from `pose`.  velocity=(vx,vy,vth) [m/s,rad/s]
+    switches the intra-scan motion distortion on."""
+    rng = np.random.default_rng((world.seed * 1000003 + t_index * 7 + seed) & 0x7fffffff)
+    img = _speckle(rng, ROWS, NBINS)
+    Tinv = np.linalg.inv(se2(*pose))
+    pts = world.static
+    if len(world.movers):
+        pts = np.vstack((pts, world.movers + world.mover_vel * (0.25 * t_index)))
+    p = (Tinv @ np.column_stack((pts, np.ones(len(pts)))).T).T[:, :2]
+    if velocity is not None:
+        v = np.asarray(velocity, float)
+        dT = 0.25 * np.arctan2(-p[:, 1], -p[:, 0]) / (2 * np.pi)
+        out = np.empty_like(p)
+        for i in range(len(p)):                                       # p_obs = SE2(v dT)^-1 p_ref
+            out[i] = (np.linalg.inv(se2(*(v * dT[i]))) @ np.array([p[i, 0], p[i, 1], 1.0]))[:2]
+        p = out
+    r = np.hypot(p[:, 0], p[:, 1]) / RANGE_RES
+    az = (np.arctan2(p[:, 1], p[:, 0]) % (2 * np.pi)) * ROWS / (2 * np.pi)
+    rows_idx = np.arange(ROWS)[:, None]
+    for ri, ai, A in zip(r, az, world.amp):
+        if ri < 20 or ri > NBINS - 20:
+            continue
+        sig_a = max(0.9, 2.2 * ROWS / (2 * np.pi * max(ri * 0.5, 1.0)) * 4.0)   # ~constant metric extent
+        sig_r = 3.0
+        a0, a1 = int(np.floor(ai - 4 * sig_a)), int(np.ceil(ai + 4 * sig_a))
+        r0, r1 = max(0, int(ri - 12)), min(NBINS, int(ri + 13))
+        aa = np.arange(a0, a1 + 1)
+        ga = np.exp(-0.5 * ((aa - ai) / sig_a) ** 2)
+        gr = np.exp(-0.5 * ((np.arange(r0, r1) - ri) / sig_r) ** 2)
+        img[np.ix_(aa % ROWS, np.arange(r0, r1))] += A * ga[:, None] * gr[None, :]
+    rec = np.zeros((ROWS, STRIDE), np.uint8)
+    ts = (timestamp_us + t_index * 250000 + (np.arange(ROWS) * 250000) // ROWS).astype(np.int64)
+    rec[:, :8] = ts.view(np.uint8).reshape(ROWS, 8)
+    enc = (13 + 14 * np.arange(ROWS)).astype(np.uint16)
+    rec[:, 8:10] = enc.view(np.uint8).reshape(ROWS, 2)
+    rec[:, 10] = 255
+    rec[:, META:] = np.clip(np.floor(img), 0, 255).astype(np.uint8)
+    return rec
+
+
+def reflector_pixels(world: World, pose, margin_px: float = 40.0):
+    """Cartesian pixel coordinates [x,y] (f32) of the static reflectors visible from `pose`
+    inside the 2024^2 image (used as the initial feature set when a test/bench does not run
+    the blob detector)."""
+    Tinv = np.linalg.inv(se2(*pose))
+    p = (Tinv @ np.column_stack((world.static, np.ones(len(world.static)))).T).T[:, :2]
+    px = p / M_PER_PX + CENTER
+    keep = (px[:, 0] > margin_px) & (px[:, 0] < 2024 - margin_px) & (px[:, 1] > margin_px) & (px[:, 1] < 2024 - margin_px)
+    keep &= np.hypot(p[:, 0], p[:, 1]) > 3.0
+    return px[keep].astype(np.float32)
+
+
+def make_sequence(seed: int, n_frames: int, n_static: int = 320, n_movers: int = 0, distortion: bool = False):
+    """-> (records list of (400,3779) u8, poses (n,3), initial features (K,2) f32)."""
+    world = World(seed, n_static, n_movers)
+    poses = trajectory(n_frames, seed)
+    recs = []
+    for t in range(n_frames):
+        vel = None
+        if distortion and t > 0:
+            d = np.linalg.inv(se2(*poses[t - 1])) @ se2(*poses[t])
+            vel = np.array([d[0, 2], d[1, 2], np.arctan2(d[1, 0], d[0, 0])]) / 0.25
+        recs.append(render_record(world, poses[t], t, vel))
+    return recs, poses, reflector_pixels(world, poses[0])

@@ -1,0 +1,69 @@
+"""GPU (-m gpu): the batched device-resident engine against the oracle's CPU restatement of
+the RawROAMSystem.run loop body, lane by lane, over several consecutive scan pairs."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-4   # m
+ANG_TOL = 1e-5   # rad
+
+
+@pytest.fixture(scope="module")
+def sequences():
+    from radarslampy_amd import synth
+    return [synth.make_sequence(seed, 4, n_movers=(12 if seed == 2 else 0), distortion=(seed == 3)) for seed in (1, 2, 3)]
+
+
+@pytest.mark.parametrize("md,reject", [(True, True), (False, True), (True, False)])
+def test_engine_matches_oracle_pipeline(sequences, md, reject):
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    ctx = _ffi.Context(0)
+    B, T = len(sequences), 4
+    eng = Engine(B, B * T, ctx=ctx, reject_outliers=reject, motion_distortion=md)
+    pipes = []
+    for b, (recs, poses, feat) in enumerate(sequences):
+        for t in range(T):
+            eng.upload_scan(b * T + t, recs[t])
+        eng.init_lane(b, b * T, feat, poses[0])
+        pipes.append(oracle.OdometryPipeline(recs[0], feat, poses[0], reject_outliers=reject, motion_distortion=md))
+    for t in range(1, T):
+        eng.step([b * T + t for b in range(B)])
+        res = eng.results()
+        for b, (recs, poses, feat) in enumerate(sequences):
+            want = pipes[b].step(recs[t])
+            got = res[b]
+            tag = (md, reject, t, b)
+            assert got["n_tracked"] == want["n_tracked"], tag
+            assert got["n_good"] == want["n_good"], tag
+            assert got["n_inliers"] == want["n_inliers"], tag
+            assert got["n_peaks"] == want["n_peaks"], tag
+            assert got["clique_proven"], tag
+            assert np.array_equal(eng.lane_features(b), pipes[b].blobCoord), tag
+            assert np.array_equal(eng.lane_peaks(b), want["peaks"]), tag
+            assert np.abs(got["h"] - want["h"]).max() <= POS_TOL, tag
+            assert abs(np.arctan2(got["R"][1, 0], got["R"][0, 0]) - np.arctan2(want["R"][1, 0], want["R"][0, 0])) <= ANG_TOL, tag
+            assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= POS_TOL, (tag, got["pose"], want["pose"])
+            assert abs(got["pose"][2] - want["pose"][2]) <= ANG_TOL, (tag, got["pose"], want["pose"])
+            assert got["new_keyframe"] == bool(want["new_keyframe"]), tag
+            assert got["retrack"] == bool(want["retrack"]), tag
+    st = eng.stage_times()
+    assert set(st) >= {"ingest_peaks", "warp_quantise", "pyramid", "klt", "max_clique", "mds_lm"}
+    eng.close()
+    ctx.close()
+
+
+def test_engine_argument_errors():
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    ctx = _ffi.Context(0)
+    eng = Engine(1, 2, ctx=ctx)
+    with pytest.raises(_ffi.RoamError):
+        eng.step([5])                       # scan index outside the pool
+    with pytest.raises(_ffi.RoamError):
+        eng.init_lane(3, 0, np.zeros((4, 2), np.float32), np.zeros(3))
+    eng.close()
+    ctx.close()
