@@ -254,7 +254,7 @@ extern "C" int32_t roam_reject_outliers(roam_ctx *ctx, const float *prev, const 
     SCRATCH(dp, float, S_IN0, sizeof(float) * 2 * (size_t)K);
     SCRATCH(dn, float, S_IN1, sizeof(float) * 2 * (size_t)K);
     SCRATCH(dadj, uint64_t, S_TMP0, sizeof(uint64_t) * (size_t)K * nw);
-    SCRATCH(dstk, uint64_t, S_TMP1, sizeof(uint64_t) * (size_t)(K + 2) * nw);
+    SCRATCH(dstk, uint64_t, S_TMP1, sizeof(uint64_t) * (size_t)(K + 2) * 2 * nw);
     SCRATCH(dmask, uint8_t, S_OUT0, (size_t)K);
     SCRATCH(dres, int32_t, S_OUT1, sizeof(int32_t) * 2);
     H2D(dp, prev, sizeof(float) * 2 * (size_t)K);
@@ -311,7 +311,7 @@ extern "C" int32_t roam_mds_solve(roam_ctx *ctx, const double *T_wj0, const doub
     H2D(dpj, p_jt, sizeof(double) * 2 * (size_t)N);
     MdsProblemDesc P;
     P.T_wj0 = dT; P.T_init = dT + 9; P.p_w = dpw; P.p_jt = dpj; P.count = nullptr;
-    P.N = N; P.nstride = N; P.B = 1; P.period = period;
+    P.N = N; P.nstride = N; P.nmax = N; P.B = 1; P.period = period;
     for (int i = 0; i < 5; i++) P.sigma5[i] = sigma5[i];
     HIP_TRY(ctx, launch_mds_solve(ctx->stream, P, dwork, dout, dint, dint + 1, dout + 6, dr0));
     double o[12];

@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const float *__r
                                                                 const float *__restrict__ next,
                                                                 const int32_t *__restrict__ count, int K,
                                                                 int kstride, double thr,
-                                                                uint64_t *__restrict__ adj, int nw)
+                                                                uint64_t *__restrict__ adj, int nw, int nws)
 {
     const int i = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wave;
-    const int Kb = count ? count[b] : K;
+    const int Kb = count ? min(count[b], K) : K;
     if (w >= nw) return;
     uint64_t word = 0;
     if (i < Kb) {
@@ -47,16 +47,17 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const float *__r
         }
         word = __ballot(e);
     }
-    if (lane == 0) adj[((int64_t)b * kstride + i) * nw + w] = word;
+    if (lane == 0) adj[((int64_t)b * kstride + i) * nws + w] = word;
 }
 
 hipError_t launch_consistency_graph(hipStream_t st, const float *prev, const float *next,
                                     const int32_t *count, int K, int kstride, int B, double thr,
-                                    uint64_t *adj, int nw)
+                                    uint64_t *adj, int nws)
 {
     if (K <= 0 || B <= 0) return hipSuccess;
+    const int nw = (K + 63) / 64;            // words that can hold a set bit
     dim3 grid((nw + 3) / 4, K, B);
-    hipLaunchKernelGGL(consistency_graph_kernel, grid, dim3(256), 0, st, prev, next, count, K, kstride, thr, adj, nw);
+    hipLaunchKernelGGL(consistency_graph_kernel, grid, dim3(256), 0, st, prev, next, count, K, kstride, thr, adj, nw, nws);
     return hipGetLastError();
 }
 
@@ -92,7 +93,7 @@ __device__ __forceinline__ uint64_t bit_if(int lane, int v) { return (lane == (v
 
 // number of colour classes of a greedy sequential colouring of P, stopping early once it
 // exceeds `need` (the caller only asks whether colours(P) > need)
-__device__ int colour_bound(uint64_t P, const uint64_t *A, int nw, int lane, int need)
+__device__ int colour_bound(uint64_t P, const uint64_t *A, int as, int nw, int lane, int need)
 {
     uint64_t U = P;
     int c = 0;
@@ -103,7 +104,7 @@ __device__ int colour_bound(uint64_t P, const uint64_t *A, int nw, int lane, int
         for (;;) {
             int v = bs_first(Q);
             if (v < 0) break;
-            uint64_t row = (lane < nw) ? A[(int64_t)v * nw + lane] : 0ull;
+            uint64_t row = (lane < nw) ? A[(int64_t)v * as + lane] : 0ull;
             uint64_t bv = bit_if(lane, v);
             Q &= ~(row | bv);
             U &= ~bv;
@@ -112,38 +113,82 @@ __device__ int colour_bound(uint64_t P, const uint64_t *A, int nw, int lane, int
     return c;
 }
 
-#define CQ_LDS_ADJ_BYTES 65536
+#define CQ_LDS_ADJ_WORDS 8192          // 64 KB of adjacency rows in LDS (compact stride)
+
+// Node reduction (wave-parallel over vertices, 64 at a time):
+//   * k-core: a vertex with fewer than (best - size) neighbours inside NP cannot belong to a
+//     clique that beats `best` -> removed, iterated to a fixed point;
+//   * universal vertices (adjacent to every other vertex of NP) belong to EVERY maximum clique
+//     of this subproblem -> moved into R at once.  Adding elements common to all candidates
+//     does not change their lexicographic order, so the canonical result is preserved.
+// Returns |NP| after reduction, or -1 when the subproblem cannot beat `best`.
+__device__ int reduce_node(uint64_t &NP, uint64_t &R, int &size, int best, const uint64_t *A, int as,
+                           int nw, int lane, uint64_t *sw)
+{
+    for (;;) {
+        const int cnt = bs_count(NP);
+        if (size + cnt <= best) return -1;
+        if (cnt == 0) return 0;
+        if (lane < 16) sw[lane] = NP;
+        __syncthreads();
+        const int thr = best - size;
+        uint64_t RM = 0, UN = 0;
+        for (int g = 0; g < nw; g++) {
+            const int u = g * 64 + lane;
+            const bool in = (sw[g] >> lane) & 1ull;
+            int d = 0;
+            if (in)
+                for (int w = 0; w < nw; w++) d += __popcll(A[(int64_t)u * as + w] & sw[w]);
+            const uint64_t brm = __ballot(in && d < thr);
+            const uint64_t bun = __ballot(in && d == cnt - 1);
+            if (lane == g) { RM = brm; UN = bun; }
+        }
+        __syncthreads();
+        if (__ballot(RM != 0)) { NP &= ~RM; continue; }
+        if (__ballot(UN != 0)) {
+            R |= UN;
+            size += bs_count(UN);
+            NP &= ~UN;
+            return bs_count(NP);
+        }
+        return cnt;
+    }
+}
 
 __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restrict__ adj_g,
                                                         const int32_t *__restrict__ count, int K, int kstride,
-                                                        int nw, long long node_limit,
+                                                        int nws, long long node_limit,
                                                         uint64_t *__restrict__ stack_g,
                                                         uint8_t *__restrict__ mask_out,
                                                         int32_t *__restrict__ n_in, int32_t *__restrict__ flags)
 {
     extern __shared__ __align__(16) unsigned char cq_smem[];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int Kb = count ? count[b] : K;
+    const int Kb = count ? min(count[b], K) : K;
     uint8_t *mask = mask_out + (int64_t)b * kstride;
     if (Kb <= 0) {
         if (lane == 0) { n_in[b] = 0; flags[b] = 1; }
         return;
     }
-    // ---- LDS carve: deg[kstride] int, vstack[kstride] short, sw[16] u64, adjacency (optional)
+    const int nw = (Kb + 63) >> 6;                 // active words per bitset
+    // ---- LDS carve: deg[K] int, lsize[K+2] short, sw[16] u64, adjacency (compact stride nw)
     int *deg = reinterpret_cast<int *>(cq_smem);
-    short *vstack = reinterpret_cast<short *>(deg + K);
-    uint64_t *sw = reinterpret_cast<uint64_t *>(cq_smem + ((sizeof(int) * K + sizeof(short) * K + 15) & ~(size_t)15));
+    short *lsize = reinterpret_cast<short *>(deg + K);
+    uint64_t *sw = reinterpret_cast<uint64_t *>(cq_smem + ((sizeof(int) * K + sizeof(short) * (K + 2) + 15) & ~(size_t)15));
     uint64_t *adj_l = sw + 16;
-    const uint64_t *Ag = adj_g + (int64_t)b * kstride * nw;
-    const bool use_lds = ((size_t)K * nw * 8 <= CQ_LDS_ADJ_BYTES);
+    const uint64_t *Ag = adj_g + (int64_t)b * kstride * nws;
+    const bool use_lds = (Kb * nw <= CQ_LDS_ADJ_WORDS);
     const uint64_t *A;
+    int as;
     if (use_lds) {
-        for (int i = lane; i < Kb * nw; i += 64) adj_l[i] = Ag[i];
-        A = adj_l;
-    } else
-        A = Ag;
+        for (int i = lane; i < Kb * nw; i += 64) {
+            const int r = i / nw, w = i - r * nw;
+            adj_l[i] = Ag[(int64_t)r * nws + w];
+        }
+        A = adj_l; as = nw;
+    } else { A = Ag; as = nws; }
     __syncthreads();
-    uint64_t *stk = stack_g + (int64_t)b * (kstride + 2) * nw;
+    uint64_t *stk = stack_g + (int64_t)b * (kstride + 2) * 2 * nws;
 
     // all-vertices set in word-per-lane layout
     uint64_t ALL = 0;
@@ -153,22 +198,17 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
         else if (Kb > lo) ALL = (1ull << (Kb - lo)) - 1ull;
     }
 
-    // ---- degrees within S (S broadcast through LDS)
-    auto degrees = [&](uint64_t S) {
-        if (lane < 16) sw[lane] = S;
-        __syncthreads();
-        for (int u = lane; u < Kb; u += 64) {
-            int dsum = 0;
-            for (int w = 0; w < nw; w++) dsum += __popcll(A[(int64_t)u * nw + w] & sw[w]);
-            deg[u] = dsum;
-        }
-        __syncthreads();
-    };
-
     // ---- greedy lower bound: peel the minimum-degree vertex (ties: largest index) until clique
     uint64_t S = ALL;
     int sizeS = Kb;
-    degrees(S);
+    if (lane < 16) sw[lane] = S;
+    __syncthreads();
+    for (int u = lane; u < Kb; u += 64) {
+        int dsum = 0;
+        for (int w = 0; w < nw; w++) dsum += __popcll(A[(int64_t)u * as + w] & sw[w]);
+        deg[u] = dsum;
+    }
+    __syncthreads();
     for (;;) {
         if (lane < 16) sw[lane] = S;
         __syncthreads();
@@ -182,71 +222,53 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
         sizeS--;
         __syncthreads();
         for (int x = lane; x < Kb; x += 64)
-            if ((A[(int64_t)x * nw + (u0 >> 6)] >> (u0 & 63)) & 1ull) deg[x]--;
+            if ((A[(int64_t)x * as + (u0 >> 6)] >> (u0 & 63)) & 1ull) deg[x]--;
         __syncthreads();
     }
     const int LB = sizeS;
-    uint64_t REC = S;               // best clique recorded so far (greedy one to start with)
-    int best = LB - 1;              // search threshold: find the lexicographically first clique of size >= LB
+    uint64_t REC = S;               // best clique recorded so far (the greedy one to start with)
+    int best = LB - 1;              // threshold: find the lexicographically first clique of size >= LB
 
-    // ---- k-core reduction: only vertices with >= LB-1 neighbours inside P can be in such a clique
-    uint64_t P = ALL;
-    for (;;) {
-        degrees(P);
-        if (lane < 16) sw[lane] = 0;
-        __syncthreads();
-        bool any = false;
-        // collect removals per word with ballots (vertex u = 64*w + lane)
-        uint64_t RM = 0;
-        for (int w = 0; w < nw; w++) {
-            int u = w * 64 + lane;
-            bool rm = (u < Kb) && (deg[u] < LB - 1);
-            uint64_t bal = __ballot(rm);
-            if (lane == w) RM = bal;
-        }
-        RM &= P;
-        any = __ballot(RM != 0) != 0;
-        if (!any) break;
-        P &= ~RM;
-    }
-
-    // ---- exact search, ascending vertex order
+    // ---- exact search in ascending vertex order (levels hold {untried candidates, R, |R|})
     long long nodes = 0;
-    int depth = 0, size = 0;
-    uint64_t R = 0;
+    int depth = -1;
     bool complete = true;
-    if (lane < nw) stk[lane] = P;
+    uint64_t NP = ALL, Rn = 0;
+    int sz = 0;
+    bool pending = true;            // (NP, Rn, sz) is a subproblem waiting to be examined
     for (;;) {
-        uint64_t cand = (lane < nw) ? stk[(int64_t)depth * nw + lane] : 0ull;
-        int v = bs_first(cand);
-        if (v >= 0 && size + bs_count(cand) <= best) v = -1;          // nothing below can improve
-        if (v < 0) {
-            if (depth == 0) break;
-            depth--;
-            size--;
-            R &= ~bit_if(lane, (int)vstack[depth]);
+        if (pending) {
+            pending = false;
+            const int c = reduce_node(NP, Rn, sz, best, A, as, nw, lane, sw);
+            if (c == 0) { if (sz > best) { best = sz; REC = Rn; } }
+            else if (c > 0) {
+                nodes++;
+                if (node_limit > 0 && nodes > node_limit) { complete = false; break; }
+                const int need = best - sz;                      // need colours(NP) > need
+                if (colour_bound(NP, A, as, nw, lane, need) > need) {
+                    depth++;
+                    if (lane < nw) {
+                        stk[((int64_t)depth * 2) * nws + lane] = NP;
+                        stk[((int64_t)depth * 2 + 1) * nws + lane] = Rn;
+                    }
+                    if (lane == 0) lsize[depth] = (short)sz;
+                }
+            }
             continue;
         }
+        if (depth < 0) break;
+        uint64_t cand = (lane < nw) ? stk[((int64_t)depth * 2) * nws + lane] : 0ull;
+        const int sl = (int)lsize[depth];
+        const int v = bs_first(cand);
+        if (v < 0 || sl + bs_count(cand) <= best) { depth--; continue; }
         cand &= ~bit_if(lane, v);
-        if (lane < nw) stk[(int64_t)depth * nw + lane] = cand;
-        uint64_t row = (lane < nw) ? A[(int64_t)v * nw + lane] : 0ull;
-        uint64_t NP = cand & row;
-        const int np = bs_count(NP);
-        if (size + 1 + np <= best) continue;
-        if (np == 0) {                                              // maximal here and strictly better
-            best = size + 1;
-            REC = R | bit_if(lane, v);
-            continue;
-        }
-        nodes++;
-        if (node_limit > 0 && nodes > node_limit) { complete = false; break; }
-        const int need = best - size - 1;                           // need colours(NP) > need
-        if (colour_bound(NP, A, nw, lane, need) <= need) continue;
-        if (lane == 0) vstack[depth] = (short)v;
-        R |= bit_if(lane, v);
-        size++;
-        depth++;
-        if (lane < nw) stk[(int64_t)depth * nw + lane] = NP;
+        if (lane < nw) stk[((int64_t)depth * 2) * nws + lane] = cand;
+        const uint64_t Rl = (lane < nw) ? stk[((int64_t)depth * 2 + 1) * nws + lane] : 0ull;
+        const uint64_t row = (lane < nw) ? A[(int64_t)v * as + lane] : 0ull;
+        NP = cand & row;
+        Rn = Rl | bit_if(lane, v);
+        sz = sl + 1;
+        pending = true;
     }
 
     // ---- emit
@@ -258,15 +280,17 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
     if (lane == 0) { n_in[b] = cnt; flags[b] = complete ? 1 : 0; }
 }
 
+// adj rows have stride nws words; stack scratch: B x (kstride+2) x 2 x nws words
 hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t *count, int K,
-                             int kstride, int nw, int B, int64_t node_limit, uint64_t *stack,
+                             int kstride, int nws, int B, int64_t node_limit, uint64_t *stack,
                              uint8_t *mask, int32_t *n_in, int32_t *flags)
 {
-    if (B <= 0) return hipSuccess;
-    size_t lds = ((sizeof(int) * (size_t)K + sizeof(short) * (size_t)K + 15) & ~(size_t)15) + 16 * 8;
-    if ((size_t)K * nw * 8 <= CQ_LDS_ADJ_BYTES) lds += (size_t)K * nw * 8;
+    if (B <= 0 || K <= 0) return hipSuccess;
+    size_t lds = ((sizeof(int) * (size_t)K + sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 16 * 8;
+    const size_t kw = (size_t)K * ((K + 63) / 64);
+    lds += 8 * (kw < CQ_LDS_ADJ_WORDS ? kw : (size_t)CQ_LDS_ADJ_WORDS);
     if (node_limit <= 0) node_limit = 300000;
-    hipLaunchKernelGGL(max_clique_kernel, dim3(B), dim3(64), lds, st, adj, count, K, kstride, nw,
+    hipLaunchKernelGGL(max_clique_kernel, dim3(B), dim3(64), lds, st, adj, count, K, kstride, nws,
                        (long long)node_limit, stack, mask, n_in, flags);
     return hipGetLastError();
 }

@@ -58,6 +58,8 @@ struct Engine {
     roam_lane_result *results = nullptr;
     hipEvent_t ev[ST_COUNT + 1];
     bool ev_ok = false, stepped = false;
+    std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
+    int kmax() const { int m = 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
     std::vector<void *> allocs;
 };
 
@@ -325,6 +327,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ctx->engine = e;
     e->cfg = *cfg;
     const int B = e->B = cfg->lanes;
+    e->lane_k.assign(B, 0);
     e->W = 2 * (cfg->clip / 2);
     e->stage_cap = (cfg->clip + 1) / 2;
     pyr_desc_init(&e->pd, e->W, e->W);
@@ -349,7 +352,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->good_idx, (size_t)B * KS);
     ok = ok && dalloc(ctx, e, &e->good_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->adj, (size_t)B * KS * nw);
-    ok = ok && dalloc(ctx, e, &e->cq_stack, (size_t)B * (KS + 2) * nw);
+    ok = ok && dalloc(ctx, e, &e->cq_stack, (size_t)B * (KS + 2) * 2 * nw);
     ok = ok && dalloc(ctx, e, &e->cq_mask, (size_t)B * KS);
     ok = ok && dalloc(ctx, e, &e->cq_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->cq_flags, (size_t)B);
@@ -406,6 +409,7 @@ int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, 
     ENGINE();
     ARG_CHECK(ctx, lane >= 0 && lane < e->B && K >= 0 && K <= KS && (K == 0 || pts));
     float *f = e->feat + (size_t)lane * KS * 2;
+    e->lane_k[lane] = K;
     if (K > 0) HIP_TRY(ctx, hipMemcpyAsync(f, pts, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(e->feat_n + lane, &K, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     // the frame that triggers a retrack also adds a keyframe at the latest pose (RawROAMSystem.py:250-270):
@@ -447,6 +451,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipStream_t st = ctx->stream;
     const roam_engine_cfg &c = e->cfg;
     const int nw = KS / 64;
+    const int KM = e->kmax();          // host-known bound: feature counts only shrink between (re)seeds
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx, scan_idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, st));
     uint8_t *prev = e->pyr[e->cur], *next = e->pyr[e->cur ^ 1];
 
@@ -458,15 +463,15 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], st));
     HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
-    HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KS, KS, B, e->klt_next, e->klt_status, e->klt_err));
+    HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KM, KS, B, e->klt_next, e->klt_status, e->klt_err));
     hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,
                        e->good_old, e->good_new, e->good_idx, e->good_n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_GRAPH], st));
     if (c.reject_outliers) {
-        HIP_TRY(ctx, launch_consistency_graph(st, e->good_old, e->good_new, e->good_n, KS, KS, B, 0.5 / M_PER_PX, e->adj, nw));
+        HIP_TRY(ctx, launch_consistency_graph(st, e->good_old, e->good_new, e->good_n, KM, KS, B, 0.5 / M_PER_PX, e->adj, nw));
         HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
-        HIP_TRY(ctx, launch_max_clique(st, e->adj, e->good_n, KS, KS, nw, B, c.clique_node_limit, e->cq_stack, e->cq_mask, e->cq_n, e->cq_flags));
+        HIP_TRY(ctx, launch_max_clique(st, e->adj, e->good_n, KM, KS, nw, B, c.clique_node_limit, e->cq_stack, e->cq_mask, e->cq_n, e->cq_flags));
     } else {
         HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
         hipLaunchKernelGGL(fill_mask_kernel, dim3(B), dim3(256), 0, st, e->cq_mask, e->good_n, e->cq_n, e->cq_flags);
@@ -476,14 +481,14 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipLaunchKernelGGL(g2_inliers_kernel, dim3(B), dim3(256), 0, st, e->good_old, e->good_new, e->good_idx, e->good_n, e->cq_mask,
                        e->kf_pose, e->kf_und, e->kf_und_tmp, e->kab_src, e->kab_tgt, e->p_w, e->p_jt, e->feat, e->in_n);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, launch_kabsch(st, e->kab_src, e->kab_tgt, e->in_n, KS, KS, B, e->kab_out));
+    HIP_TRY(ctx, launch_kabsch(st, e->kab_src, e->kab_tgt, e->in_n, KM, KS, B, e->kab_out));
     hipLaunchKernelGGL(g3_init_transform_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->kab_out, e->pose, e->T_wj0, e->T_init, B);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_LM], st));
     if (c.motion_distortion) {
         MdsProblemDesc P;
         P.T_wj0 = e->T_wj0; P.T_init = e->T_init; P.p_w = e->p_w; P.p_jt = e->p_jt; P.count = e->in_n;
-        P.N = KS; P.nstride = KS; P.B = B; P.period = 0.25;
+        P.N = KM; P.nstride = KS; P.nmax = KM; P.B = B; P.period = 0.25;
         for (int i = 0; i < 5; i++) P.sigma5[i] = c.sigma5[i];
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }

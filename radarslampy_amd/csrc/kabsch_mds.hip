@@ -279,12 +279,12 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
     extern __shared__ __align__(16) unsigned char lm_smem[];
     __shared__ LmShared S;
     const int b = blockIdx.x, t = threadIdx.x;
-    const int N = P.count ? P.count[b] : P.N;
+    const int N = P.count ? min(P.count[b], P.nmax) : P.N;
     const int m = 2 * N + 3, n = 6;
-    const int mmax = 2 * P.nstride + 3;
-    const size_t need = ((size_t)mmax * 9 + P.nstride) * sizeof(double);
+    const int mmax = 2 * P.nmax + 3;
+    const size_t need = ((size_t)mmax * 9 + P.nmax) * sizeof(double);
     double *work = (need <= LM_LDS_BYTES) ? reinterpret_cast<double *>(lm_smem)
-                                          : work_g + (size_t)b * ((size_t)mmax * 9 + P.nstride);
+                                          : work_g + (size_t)b * ((size_t)mmax * 9 + P.nmax);
     double *fvec = work, *a = work + mmax, *wa4 = a + (size_t)6 * mmax, *wf = wa4 + mmax, *dT = wf + mmax;
     // NOTE: columns of `a` are spaced m apart (A_ macro), all inside the 6*mmax slab.
     const double *p_w = P.p_w + (size_t)b * P.nstride * 2;
@@ -537,8 +537,8 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
                             int32_t *nfev, int32_t *info, double *x0_out, double *r0_out)
 {
     if (p.B <= 0) return hipSuccess;
-    const size_t mmax = 2 * (size_t)p.nstride + 3;
-    size_t need = (mmax * 9 + p.nstride) * sizeof(double);
+    const size_t mmax = 2 * (size_t)p.nmax + 3;
+    size_t need = (mmax * 9 + p.nmax) * sizeof(double);
     size_t lds = need <= LM_LDS_BYTES ? need : 0;
     hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(LM_T), lds, st, p, work, out6, nfev, info, x0_out, r0_out);
     return hipGetLastError();

@@ -106,7 +106,7 @@ hipError_t launch_klt(hipStream_t st, const uint8_t *prev_pyr, const uint8_t *ne
 hipError_t launch_consistency_graph(hipStream_t st, const float *prev, const float *next,
                                     const int32_t *count, int K, int kstride, int B, double thr,
                                     uint64_t *adj, int nw);
-// max clique (lexicographically smallest maximum clique); stack scratch: B x (K+2) x nw words
+// max clique (lexicographically smallest maximum clique); stack scratch: B x (kstride+2) x 2 x nw words
 hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t *count, int K,
                              int kstride, int nw, int B, int64_t node_limit, uint64_t *stack,
                              uint8_t *mask, int32_t *n_in, int32_t *flags);
@@ -122,10 +122,11 @@ struct MdsProblemDesc {
     const double *T_init;    // B x 9
     const int32_t *count;    // B (or null -> N)
     int N, nstride, B;
+    int nmax;                // upper bound of count[] (sizes the LM working set); <= nstride
     double sigma5[5];
     double period;
 };
-// work: B x (2*nstride+3) x 9 doubles; out6: B x 6; nfev/info: B; x0/r0 optional
+// work: B x ((2*nmax+3) x 9 + nmax) doubles; out6: B x 6; nfev/info: B; x0/r0 optional
 hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *work, double *out6,
                             int32_t *nfev, int32_t *info, double *x0_out, double *r0_out);
 hipError_t launch_mds_undistort(hipStream_t st, const double *v3, const double *pts, int N,

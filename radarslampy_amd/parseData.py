@@ -1,0 +1,34 @@
+"""Oxford record decode + polar->Cartesian warp with the reference's names
+(reference parseData.py:9-53,100-135).  The warp runs on the MI355X (warp.hip)."""
+import numpy as np
+
+from . import _ffi
+
+RANGE_RESOLUTION_M = 0.0432                                   # parseData.py:9
+DOWNSAMPLE_FACTOR = 2                                         # parseData.py:10
+RANGE_RESOLUTION_CART_M = RANGE_RESOLUTION_M * DOWNSAMPLE_FACTOR   # parseData.py:13
+MAX_RANGE_CLIP_DEFAULT = 87.5                                 # parseData.py:14
+
+
+def extractDataFromRadarImage(polarImgData: np.ndarray, maxRangeClipM: float = MAX_RANGE_CLIP_DEFAULT):
+    """Split a (400, 3779) u8 record into (range_azimuth_data f32, azimuths, range_resolution,
+    azimuth_resolution, valid, timestamps) exactly like parseData.py:17-53.  (The engine never
+    materialises the f32 image: its kernels read the u8 payload directly.)"""
+    encoder_size = 5600
+    timestamps = polarImgData[:, :8].copy().view(np.int64)
+    azimuths = (polarImgData[:, 8:10].copy().view(np.uint16) / float(encoder_size) * 2 * np.pi).astype(np.float32)
+    valid = polarImgData[:, 10:11] == 255
+    data = polarImgData[:, 11:].astype(np.float32) / 255.
+    if maxRangeClipM > 0:
+        data = data[:, :int(maxRangeClipM / RANGE_RESOLUTION_M)]
+    return data, azimuths, RANGE_RESOLUTION_M, azimuths[1] - azimuths[0], valid, timestamps
+
+
+def convertPolarImageToCartesian(imgPolar: np.ndarray, logPolarMode: bool = False,
+                                 downsampleFactor: int = DOWNSAMPLE_FACTOR,
+                                 changeGlobalRangeResolution: bool = False) -> np.ndarray:
+    """(rows, cols) f32 polar -> (2R, 2R) f32 Cartesian, R = cols // 2 (parseData.py:100-135)."""
+    if logPolarMode or downsampleFactor != 2:
+        raise NotImplementedError("only the reference's live configuration (linear, downsampleFactor=2) is built")
+    cart, _ = _ffi.default_context().polar_to_cart_f32(imgPolar, want_f32=True, want_u8=False)
+    return cart
