@@ -177,6 +177,8 @@ int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
 /* blocking: current feature set of a lane (cap rows), and its peak list */
 int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t lane, float *pts, int32_t cap, int32_t *K);
 int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_t cap, int64_t *n);
+/* blocking: level `level` (0..3) of the lane's most recent Cartesian u8 pyramid (w*h bytes, row-major) */
+int32_t roam_engine_lane_image(roam_ctx *ctx, int32_t lane, int32_t level, uint8_t *out, int64_t cap);
 /* replace a lane's feature set (retrack append, getFeatures.appendNewFeatures getFeatures.py:98-118) */
 int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, int32_t K);
 /* per-stage device time of the last step in milliseconds (hipEvent pairs on the stream);

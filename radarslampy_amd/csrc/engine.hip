@@ -35,6 +35,7 @@ struct Engine {
     size_t rec_bytes = 0;
     uint8_t *pool = nullptr;
     uint8_t *pyr[2] = {nullptr, nullptr};
+    uint32_t *warp_map = nullptr;       // W x W sampling map (geometry only)
     int cur = 0;                        // pyr[cur] = previous image pyramids
     uint16_t *row_stage = nullptr;
     int32_t *row_count = nullptr, *peaks_out = nullptr, *peaks_n = nullptr;
@@ -318,7 +319,8 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
 {
     if (!ctx) return ROAM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ARG_CHECK(ctx, cfg && cfg->lanes >= 1 && cfg->rows >= 1 && cfg->clip >= 32 && cfg->clip <= ROAM_MAX_COLS &&
+    ARG_CHECK(ctx, cfg && cfg->lanes >= 1 && cfg->rows >= 1 && cfg->rows <= 1020 && cfg->clip >= 32 && cfg->clip <= 4094 && (cfg->clip / 2) % 2 == 0 &&
+                       (int64_t)cfg->rows * cfg->stride < (1ll << 30) &&
                        cfg->payload_off >= 0 && cfg->stride >= cfg->payload_off + cfg->clip && cfg->pool_scans >= 1 &&
                        cfg->peaks_cap >= 1);
     roam_engine_destroy(ctx);
@@ -337,6 +339,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->pool, e->rec_bytes * cfg->pool_scans);
     ok = ok && dalloc(ctx, e, &e->pyr[0], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[1], (size_t)e->pd.lane_stride * B);
+    ok = ok && dalloc(ctx, e, &e->warp_map, (size_t)e->W * e->W);
     ok = ok && dalloc(ctx, e, &e->row_stage, (size_t)B * cfg->rows * e->stage_cap);
     ok = ok && dalloc(ctx, e, &e->row_count, (size_t)B * cfg->rows);
     ok = ok && dalloc(ctx, e, &e->peaks_out, (size_t)B * cfg->peaks_cap * 2);
@@ -379,6 +382,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     }
     e->ev_ok = true;
+    HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
 }
@@ -433,7 +437,7 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
     // previous-image pyramid of this lane from the pool scan
     uint8_t *pyr = e->pyr[e->cur] + (size_t)lane * e->pd.lane_stride;
     WarpSrc ws = {e->pool + (size_t)pool_idx * e->rec_bytes, 0, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, nullptr};
-    HIP_TRY(ctx, launch_polar_to_cart(ctx->stream, ws, 1, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride, nullptr, 0));
+    HIP_TRY(ctx, launch_warp_gather(ctx->stream, e->warp_map, ws, 1, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride));
     HIP_TRY(ctx, launch_build_pyramid(ctx->stream, pyr, e->pd, 1));
     double zero[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane, pose3, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
@@ -459,7 +463,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};
     HIP_TRY(ctx, launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], st));
-    HIP_TRY(ctx, launch_polar_to_cart(st, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride, nullptr, 0));
+    HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], st));
     HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
@@ -546,6 +550,18 @@ int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_
     return (n > cap || n > e->cfg.peaks_cap) ? ROAM_E_CAPACITY : ROAM_OK;
 }
 
+int32_t roam_engine_lane_image(roam_ctx *ctx, int32_t lane, int32_t level, uint8_t *out, int64_t cap)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && level >= 0 && level < ROAM_PYR_LEVELS && out);
+    const size_t n = (size_t)e->pd.w[level] * e->pd.h[level];
+    ARG_CHECK(ctx, cap >= (int64_t)n);
+    HIP_TRY(ctx, hipMemcpyAsync(out, e->pyr[e->cur] + (size_t)lane * e->pd.lane_stride + e->pd.off[level], n,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
 int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap, int32_t *n)
 {
     ENGINE();
@@ -582,7 +598,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     HIP_TRY(ctx, hipEventRecord(a, st));
     for (int r = 0; r < reps; r++) {
         if (!strcmp(name, "warp_quantise")) {
-            HIP_TRY(ctx, launch_polar_to_cart(st, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride, nullptr, 0));
+            HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride));
             bytes = (double)B * ((double)c.rows * c.clip + (double)e->W * e->W);
         } else if (!strcmp(name, "ingest_peaks")) {
             PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
     if (U8) {
         const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
                            (int64_t)r * src.row_stride + src.payload_off;
-        for (int i = t; i < cols; i += PK_T) xs[i] = __fdiv_rn((float)p[i], 255.f);
+        for (int i = t; i < cols; i += PK_T) xs[i] = (float)__dmul_rn((double)p[i], 1.0 / 255.0);   // == (float)k/255.f for all 256 codes
     } else {
         const float *p = reinterpret_cast<const float *>(src.base) + lane_sel * src.lane_stride +
                          (int64_t)r * src.row_stride;

@@ -127,6 +127,129 @@ __global__ __launch_bounds__(256) void polar_to_cart_kernel(WarpSrc src, int row
     }
 }
 
+// ------------------------------------------------------------------------------ map path
+// The sampling map (sx, sy in 1/32 px) depends only on the geometry (rows, cols), not on
+// the scan: the engine computes it ONCE with the exact arithmetic of warp_pixel and every
+// later warp is a pure gather: 4 B of map per pixel shared by LB lanes of the batch, four
+// u8 taps through L1/L2, 7 float ops, one packed 32-bit store per 4 pixels.
+// u8 -> float32 decode: (float)((double)k * (1.0/255.0)) == (float)k / 255.f for all 256
+// codes (verified exhaustively in tests/test_abi_cpu.py) - 3 cheap ops instead of a divide.
+__device__ __forceinline__ float code_to_f32(uint32_t k)
+{
+    return (float)__dmul_rn((double)k, 1.0 / 255.0);
+}
+
+// pack: ix [0,12) | iy [12,22) | fx [22,27) | fy [27,32)
+__global__ __launch_bounds__(256) void warp_map_kernel(int rows, int cols, int R, uint32_t *__restrict__ map)
+{
+    const int W = 2 * R;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const double Kangle = 6.283185307179586476925286766559 / (double)rows;
+    const double Kmag = (double)R / (double)cols;
+    const float fx = __fsub_rn((float)x, (float)R);
+    const float fy = __fsub_rn((float)y, (float)R);
+    const float mag = rn_sqrtf(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)));
+    const float ang = __fmul_rn(fast_atan2_deg(fy, fx), (float)(3.14159265358979323846 / 180.0));
+    const double rho = __ddiv_rn((double)mag, Kmag);
+    const double phi = __ddiv_rn((double)ang, Kangle);
+    const float mx = (float)rho;
+    const float my = __fadd_rn((float)phi, 1.f);
+    const int sx = __float2int_rn(__fmul_rn(mx, 32.f));
+    const int sy = __float2int_rn(__fmul_rn(my, 32.f));
+    int ix = sx >> 5, iy = sy >> 5;
+    if (ix > 4095) ix = 4095;                   // >= cols: both taps read zero anyway
+    if (ix < 0) ix = 4095;
+    if (iy < 0) iy = 0;
+    if (iy > 1022) iy = 1022;
+    map[(int64_t)y * W + x] = (uint32_t)ix | ((uint32_t)iy << 12) | ((uint32_t)(sx & 31) << 22) | ((uint32_t)(sy & 31) << 27);
+}
+
+hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
+{
+    const int R = cols / 2, W = 2 * R;
+    hipLaunchKernelGGL(warp_map_kernel, dim3((W + 255) / 256, W), dim3(256), 0, st, rows, cols, R, map);
+    return hipGetLastError();
+}
+
+#define WG_LB 8
+#define WG_TW 64          // tile width  (one wavefront = 64 consecutive pixels of a row:
+#define WG_TH 16          // tile height  their taps fall into 1-2 cache lines per polar row)
+// 256-thread block = 64 x 16 pixel tile; wave w owns rows 4w..4w+3, lane = x offset.  Compact
+// 2-D tiles keep the polar footprint of a block to a few 128-B lines that stay in L1 across
+// the 4 taps, the 16 rows and the LB lanes.  Results are transposed through a 1 KB LDS tile so
+// that the global stores are whole dwords (64 B contiguous per row and wave).
+__global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__restrict__ map, const uint8_t *__restrict__ pool,
+                                                          int64_t lane_stride, int64_t row_stride, int payload_off,
+                                                          const int32_t *__restrict__ lane_index, int B, int rows,
+                                                          int cols, int W, uint8_t *__restrict__ cart_u8,
+                                                          int64_t u8_lane_stride)
+{
+    __shared__ __align__(16) uint8_t tile[WG_TH][WG_TW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * WG_TW + lane;
+    const int y0 = blockIdx.y * WG_TH;
+    const bool xin = x < W;
+    int off0[4], off1[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    bool in0[4], in1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int y = y0 + wv * 4 + j;
+        const bool ok = xin && y < W;
+        const uint32_t m = ok ? map[(int64_t)y * W + x] : 4095u;
+        const int ix = m & 4095, iy = (m >> 12) & 1023;
+        const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+        const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+        w00[j] = __fmul_rn(wy0, wx0); w01[j] = __fmul_rn(wy0, wx1);
+        w10[j] = __fmul_rn(wy1, wx0); w11[j] = __fmul_rn(wy1, wx1);
+        int r0 = iy - 1, r1 = iy;
+        if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
+        if (r1 >= rows) r1 -= rows;
+        off0[j] = r0 * (int)row_stride + ix;
+        off1[j] = r1 * (int)row_stride + ix;
+        in0[j] = ok && ix < cols; in1[j] = ok && ix + 1 < cols;
+    }
+    // dword owned by this thread in the store phase
+    const int srow = threadIdx.x >> 4, scol = (threadIdx.x & 15) * 4;
+    const int sy = y0 + srow, sx = blockIdx.x * WG_TW + scol;
+    const bool sok = sy < W && sx + 3 < W;
+    const int l0 = blockIdx.z * WG_LB, l1 = min(B, l0 + WG_LB);
+    for (int l = l0; l < l1; l++) {
+        const int64_t sel = lane_index ? (int64_t)lane_index[l] : (int64_t)l;
+        const uint8_t *p = pool + sel * lane_stride + payload_off;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float s00 = in0[j] ? code_to_f32(p[off0[j]]) : 0.f;
+            const float s01 = in1[j] ? code_to_f32(p[off0[j] + 1]) : 0.f;
+            const float s10 = in0[j] ? code_to_f32(p[off1[j]]) : 0.f;
+            const float s11 = in1[j] ? code_to_f32(p[off1[j] + 1]) : 0.f;
+            float v = __fmul_rn(s00, w00[j]);
+            v = __fadd_rn(v, __fmul_rn(s01, w01[j]));
+            v = __fadd_rn(v, __fmul_rn(s10, w10[j]));
+            v = __fadd_rn(v, __fmul_rn(s11, w11[j]));
+            tile[wv * 4 + j][lane] = (uint8_t)quant_u8(v);
+        }
+        __syncthreads();
+        if (sok)
+            *reinterpret_cast<uint32_t *>(cart_u8 + (int64_t)l * u8_lane_stride + (int64_t)sy * W + sx) =
+                *reinterpret_cast<const uint32_t *>(&tile[srow][scol]);
+        __syncthreads();
+    }
+}
+
+// requires W % 4 == 0, u8_lane_stride % 4 == 0, rows * row_stride + cols < 2^31
+hipError_t launch_warp_gather(hipStream_t st, const uint32_t *map, WarpSrc src, int B, int rows, int cols,
+                              uint8_t *cart_u8, int64_t u8_lane_stride)
+{
+    const int R = cols / 2, W = 2 * R;
+    dim3 grid((W + WG_TW - 1) / WG_TW, (W + WG_TH - 1) / WG_TH, (B + WG_LB - 1) / WG_LB);
+    hipLaunchKernelGGL(warp_gather_kernel, grid, dim3(256), 0, st, map, reinterpret_cast<const uint8_t *>(src.base),
+                       src.lane_stride, src.row_stride, src.payload_off, src.lane_index, B, rows, cols, W, cart_u8,
+                       u8_lane_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_polar_to_cart(hipStream_t st, WarpSrc src, int B, int rows, int cols,
                                 uint8_t *cart_u8, int64_t u8_lane_stride, float *cart_f32,
                                 int64_t f32_lane_stride)

@@ -77,6 +77,14 @@ class Engine:
         self.ctx.check(self.lib.roam_engine_lane_peaks(self.ctx.h, int(lane), _ffi._ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def lane_image(self, lane: int, level: int = 0):
+        W = 2 * (self.cfg.clip // 2)
+        for _ in range(level):
+            W = (W + 1) // 2
+        out = np.empty((W, W), np.uint8)
+        self.ctx.check(self.lib.roam_engine_lane_image(self.ctx.h, int(lane), int(level), _ffi._ptr(out), out.size))
+        return out
+
     def stage_times(self):
         ms = (C.c_float * 16)()
         names = (C.c_char_p * 16)()

@@ -115,3 +115,12 @@ def test_synthetic_record_layout():
     assert 5 < data.mean() * 255 < 20 and feat.shape[0] > 100
     recs2, _, _ = synth.make_sequence(3, 2)
     assert np.array_equal(recs[1], recs2[1])        # seeded, reproducible
+
+
+def test_u8_decode_identity():
+    """The kernels decode power codes as (float)((double)k * (1.0/255.0)); this equals the
+    reference's float32 division k/255 (parseData.py:40) for every one of the 256 codes."""
+    k = np.arange(256)
+    ref = k.astype(np.float32) / np.float32(255.)
+    got = (k.astype(np.float64) * (1.0 / 255.0)).astype(np.float32)
+    assert np.array_equal(got, ref)

@@ -43,6 +43,9 @@ def test_engine_matches_oracle_pipeline(sequences, md, reject):
             assert got["n_peaks"] == want["n_peaks"], tag
             assert got["clique_proven"], tag
             assert np.array_equal(eng.lane_features(b), pipes[b].blobCoord), tag
+            if md and reject:
+                for lvl in range(4):      # map+gather warp and the pyramid are bit-exact
+                    assert np.array_equal(eng.lane_image(b, lvl), pipes[b].prevPyr[lvl]), (tag, lvl)
             assert np.array_equal(eng.lane_peaks(b), want["peaks"]), tag
             assert np.abs(got["h"] - want["h"]).max() <= POS_TOL, tag
             assert abs(np.arctan2(got["R"][1, 0], got["R"][0, 0]) - np.arctan2(want["R"][1, 0], want["R"][0, 0])) <= ANG_TOL, tag
