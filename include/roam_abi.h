@@ -122,10 +122,13 @@ int32_t roam_ssc(roam_ctx *ctx, const double *kp, int32_t B, int32_t num_ret, do
                  int32_t cols, int32_t rows, int32_t *sel_out, int32_t *n_sel);
 
 /* ---- a4: getFeatures.getBlobsFromCart (skimage blob_doh, getFeatures.py:22-53) ------------
- * img w x h f32 -> blobs (cap,3) f64 rows [row, col, sigma]. */
-int32_t roam_doh_blobs(roam_ctx *ctx, const float *img, int32_t w, int32_t h, double min_sigma,
-                       double max_sigma, int32_t num_sigma, double threshold, double overlap,
-                       double *blobs_out, int32_t cap, int32_t *n_out);
+ * image-scale part of blob_doh: float64 integral image, box-filter Hessian determinant for
+ * every sigma, 3x3x3 local maxima above `threshold`.  img w x h f32.  out_rcs (cap,3) int32 rows
+ * [row, col, sigma_index] in C (row, col, sigma) order, out_val (cap) the determinant values.
+ * Ordering by response and overlap pruning (_prune_blobs) are host bookkeeping. */
+int32_t roam_doh_maxima(roam_ctx *ctx, const float *img, int32_t w, int32_t h, const double *sigmas,
+                        int32_t num_sigma, double threshold, int32_t *out_rcs, double *out_val,
+                        int32_t cap, int32_t *n_out);
 
 /* ---- engine: B resident lanes, one scan pair per lane per step ---------------------------
  * Replaces the body of the RawROAMSystem.run loop (RawROAMSystem.py:162-298) minus plotting:

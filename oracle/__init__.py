@@ -334,6 +334,89 @@ def ssc(keypoints, num_ret_points, tolerance, cols, rows):
     return kp[sel[:n]]
 
 
+def doh_maxima(img, sigma_list, threshold, cap=1 << 18):
+    """integral image + Hessian determinants + 3x3x3 maxima (oracle/c/doh.c) -> (rcs, values)"""
+    img = np.ascontiguousarray(img, np.float32)
+    H, W = img.shape
+    S = np.empty((H, W), np.float64)
+    lib().oracle_integral_image(_p(img, C.c_float), H, W, _p(S, C.c_double))
+    layers = []
+    for s in sigma_list:
+        if int(3 * s) <= 0:
+            layers.append(None)
+            continue
+        d = np.empty((H, W), np.float64)
+        lib().oracle_hessian_det(_p(S, C.c_double), H, W, C.c_double(float(s)), _p(d, C.c_double))
+        layers.append(d)
+    arr = (C.POINTER(C.c_double) * len(layers))(*[(_p(l, C.c_double) if l is not None else None) for l in layers])
+    rcs = np.empty((cap, 3), np.int32)
+    val = np.empty(cap, np.float64)
+    lib().oracle_doh_maxima.restype = C.c_int64
+    n = lib().oracle_doh_maxima(arr, len(layers), H, W, C.c_double(float(threshold)), _p(rcs, C.c_int32), _p(val, C.c_double),
+                                C.c_int64(cap))
+    assert n <= cap
+    return rcs[:n], val[:n], layers
+
+
+def _overlap2d(b1, b2):
+    import math
+    if b1[2] == b2[2] == 0:
+        return 0.0
+    if b1[2] > b2[2]:
+        ms, r1, r2 = b1[2], 1.0, b2[2] / b1[2]
+    else:
+        ms, r2, r1 = b2[2], 1.0, b1[2] / b2[2]
+    d = math.hypot((b2[0] - b1[0]) / (ms * math.sqrt(2)), (b2[1] - b1[1]) / (ms * math.sqrt(2)))
+    if d > r1 + r2:
+        return 0.0
+    if d <= abs(r1 - r2):
+        return 1.0
+    q1 = min(1.0, max(-1.0, (d * d + r1 * r1 - r2 * r2) / (2 * d * r1)))
+    q2 = min(1.0, max(-1.0, (d * d + r2 * r2 - r1 * r1) / (2 * d * r2)))
+    area = r1 * r1 * math.acos(q1) + r2 * r2 * math.acos(q2) - 0.5 * math.sqrt(abs((-d + r2 + r1) * (d - r2 + r1) * (d + r2 - r1) * (d + r2 + r1)))
+    return area / (math.pi * min(r1, r2) ** 2)
+
+
+def blob_doh(image, min_sigma=1, max_sigma=30, num_sigma=10, threshold=0.01, overlap=0.5):
+    """skimage.feature.blob_doh restatement (getFeatures.py:47-51): maxima ordered by response,
+    then _prune_blobs with the candidate pairs taken in ascending (i, j) order (brute-force
+    pair search here, independent of the product's k-d tree)."""
+    sig = np.linspace(min_sigma, max_sigma, num_sigma)
+    rcs, val, _ = doh_maxima(image, sig, threshold)
+    if len(rcs) == 0:
+        return np.empty((0, 3))
+    idx = np.argsort(-val)
+    bl = rcs[idx].astype(np.float64)
+    bl[:, 2] = sig[rcs[idx][:, 2]]
+    dist = 2 * bl[:, 2].max() * np.sqrt(2)
+    order = np.argsort(bl[:, 0], kind="stable")
+    rows = bl[order, 0]
+    n = len(bl)
+    pairs = []
+    for a in range(n):                                   # sweep over rows: candidates within `dist` rows
+        i = order[a]
+        hi = np.searchsorted(rows, rows[a] + dist, side="right")
+        js = order[a + 1:hi]
+        if len(js):
+            d2 = (bl[js, 0] - bl[i, 0]) ** 2 + (bl[js, 1] - bl[i, 1]) ** 2
+            for j in js[d2 <= dist * dist]:
+                pairs.append((min(i, j), max(i, j)))
+    for i, j in sorted(pairs):
+        if _overlap2d(bl[i], bl[j]) > overlap:
+            if bl[i, 2] > bl[j, 2]:
+                bl[j, 2] = 0
+            else:
+                bl[i, 2] = 0
+    return bl[bl[:, 2] > 0]
+
+
+def getFeatures(img):
+    """getFeatures.py:74-95 with DEFAULT_FEATURE_PARAMS (:13-18)."""
+    blobs = blob_doh(np.asarray(img, np.float64), min_sigma=0.01, max_sigma=10, num_sigma=3, threshold=.0005)
+    blobs = adaptiveNMS(img.shape, blobs)
+    return np.fliplr(blobs[:, :2]), blobs[:, 2]
+
+
 def adaptiveNMS(img_shape, blobs, ret_points=200, tolerance=0.1):
     """getFeatures.py:66-72."""
     H, W = img_shape

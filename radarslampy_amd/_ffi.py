@@ -54,7 +54,7 @@ _SIGS = {
     "roam_mds_solve": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_double, _vp, _P(C.c_int32), _P(C.c_int32), _vp, _vp]),
     "roam_mds_undistort": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
     "roam_ssc": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, _vp, _P(C.c_int32)]),
-    "roam_doh_blobs": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double, _vp, C.c_int32, _P(C.c_int32)]),
+    "roam_doh_maxima": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_double, _vp, _vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_create": (C.c_int32, [_vp, _P(EngineCfg)]),
     "roam_engine_destroy": (C.c_int32, [_vp]),
     "roam_engine_upload_scan": (C.c_int32, [_vp, C.c_int32, _vp]),
@@ -238,14 +238,17 @@ class Context:
         self.check(self.lib.roam_ssc(self.h, _ptr(kp), B, int(num_ret), float(tol), int(cols), int(rows), _ptr(sel), C.byref(n)))
         return sel[:n.value]
 
-    def doh_blobs(self, img, min_sigma, max_sigma, num_sigma, threshold, overlap=0.5, cap=1 << 16):
+    def doh_maxima(self, img, sigmas, threshold, cap=1 << 18):
+        """-> (rcs (n,3) int32 [row, col, sigma_index] in C order, values (n,) f64)"""
         img = np.ascontiguousarray(img, np.float32)
         h, w = img.shape
-        out = np.empty((cap, 3), np.float64)
+        sig = np.ascontiguousarray(sigmas, np.float64)
+        rcs = np.empty((cap, 3), np.int32)
+        val = np.empty(cap, np.float64)
         n = C.c_int32(0)
-        self.check(self.lib.roam_doh_blobs(self.h, _ptr(img), w, h, float(min_sigma), float(max_sigma), int(num_sigma),
-                                           float(threshold), float(overlap), _ptr(out), cap, C.byref(n)))
-        return out[:n.value]
+        self.check(self.lib.roam_doh_maxima(self.h, _ptr(img), w, h, _ptr(sig), len(sig), float(threshold), _ptr(rcs),
+                                            _ptr(val), cap, C.byref(n)))
+        return rcs[:n.value], val[:n.value]
 
 
 _default = {}

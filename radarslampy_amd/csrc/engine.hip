@@ -626,11 +626,4 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     return ROAM_OK;
 }
 
-int32_t roam_doh_blobs(roam_ctx *ctx, const float *, int32_t, int32_t, double, double, int32_t, double, double, double *, int32_t, int32_t *)
-{
-    if (!ctx) return ROAM_E_ARG;
-    ROAM_SET_ERR(ctx, "doh not built yet");
-    return ROAM_E_STATE;
-}
-
 }  // extern "C"

@@ -1,5 +1,7 @@
 """Feature (re)detection with the reference's names (reference getFeatures.py:13-118):
 Determinant-of-Hessian blobs (doh.hip) + SSC-ANMS (ssc.hip) + dedupe-append."""
+import math
+
 import numpy as np
 
 from . import _ffi
@@ -14,11 +16,69 @@ def calculateFeatureLossThreshold(nInitialFeatures):
     return 80
 
 
-def getBlobsFromCart(cartImage: np.ndarray, min_sigma=1, max_sigma=30, num_sigma=10, threshold=0.01, method="doh") -> np.ndarray:
-    """-> (K,3) [r, c, sigma] (getFeatures.py:22-53; only the live method 'doh' is built)."""
+def _disk_overlap(d, r1, r2):
+    ratio1 = np.clip((d ** 2 + r1 ** 2 - r2 ** 2) / (2 * d * r1), -1, 1)
+    ratio2 = np.clip((d ** 2 + r2 ** 2 - r1 ** 2) / (2 * d * r2), -1, 1)
+    a, b, c, dd = -d + r2 + r1, d - r2 + r1, d + r2 - r1, d + r2 + r1
+    area = r1 ** 2 * math.acos(ratio1) + r2 ** 2 * math.acos(ratio2) - 0.5 * math.sqrt(abs(a * b * c * dd))
+    return area / (math.pi * (min(r1, r2) ** 2))
+
+
+def _blob_overlap(b1, b2):
+    """skimage.feature.blob._blob_overlap for 2-D blobs [row, col, sigma]."""
+    root2 = math.sqrt(2)
+    if b1[2] == b2[2] == 0:
+        return 0.0
+    if b1[2] > b2[2]:
+        ms, r1, r2 = b1[2], 1.0, b2[2] / b1[2]
+    else:
+        ms, r2, r1 = b2[2], 1.0, b1[2] / b2[2]
+    d = math.sqrt(((b2[0] - b1[0]) / (ms * root2)) ** 2 + ((b2[1] - b1[1]) / (ms * root2)) ** 2)
+    if d > r1 + r2:
+        return 0.0
+    if d <= abs(r1 - r2):
+        return 1.0
+    return _disk_overlap(d, r1, r2)
+
+
+def _prune_blobs(blobs, overlap):
+    """skimage.feature.blob._prune_blobs.  scikit-image walks the candidate pairs in the
+    iteration order of a Python set (not reproducible); here they are walked in ascending
+    (i, j) order of the response-sorted blob array - documented in DESIGN.md."""
+    from scipy import spatial
+    sigma = blobs[:, -1].max()
+    distance = 2 * sigma * math.sqrt(blobs.shape[1] - 1)
+    pairs = spatial.cKDTree(blobs[:, :-1]).query_pairs(distance, output_type="ndarray")
+    if len(pairs) == 0:
+        return blobs
+    pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
+    blobs = blobs.copy()
+    for i, j in pairs:
+        b1, b2 = blobs[i], blobs[j]
+        if _blob_overlap(b1, b2) > overlap:
+            if b1[-1] > b2[-1]:
+                b2[-1] = 0
+            else:
+                b1[-1] = 0
+    return blobs[blobs[:, -1] > 0]
+
+
+def getBlobsFromCart(cartImage: np.ndarray, min_sigma=1, max_sigma=30, num_sigma=10, threshold=0.01, method="doh",
+                     overlap=0.5) -> np.ndarray:
+    """-> (K,3) [r, c, sigma] (getFeatures.py:22-53; only the live method 'doh' is built).
+    Image-scale work (integral image, Hessian determinants, 3x3x3 maxima) runs on the MI355X
+    (doh.hip); the response ordering / sigma lookup / overlap pruning below follow
+    skimage.feature.blob_doh (peak_local_max ordering, _prune_blobs)."""
     if method != "doh":
         raise NotImplementedError(f"{method} not implemented! Use 'doh'")
-    return _ffi.default_context().doh_blobs(cartImage, min_sigma, max_sigma, num_sigma, threshold, 0.5)
+    sigma_list = np.linspace(min_sigma, max_sigma, num_sigma)
+    rcs, val = _ffi.default_context().doh_maxima(cartImage, sigma_list, threshold)
+    if len(rcs) == 0:
+        return np.empty((0, 3))
+    idx = np.argsort(-val)                        # peak_local_max: highest response first
+    lm = rcs[idx].astype(np.float64)
+    lm[:, -1] = sigma_list[rcs[idx][:, -1]]
+    return _prune_blobs(lm, overlap)
 
 
 def adaptiveNMS(img, blobs, ret_points=200, tolerance=0.1):

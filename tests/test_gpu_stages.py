@@ -255,3 +255,37 @@ def test_ssc(ctx, golden):
     kp = np.column_stack((rng.integers(0, 2024, (50, 2)).astype(float), np.full(50, 5.005)))
     sel = ctx.ssc(kp, 200, 0.1, 2024, 2024)          # pairwise (tiny-width) mode
     assert np.array_equal(kp[sel], oracle.ssc(kp, 200, 0.1, 2024, 2024))
+
+
+# ------------------------------------------------------------------ a4 DoH + a5/a6 feature detection
+def test_doh_maxima_bit_exact(ctx, cart_pair):
+    cart = cart_pair[0][0]
+    sig = np.linspace(0.01, 10, 3)
+    want_rcs, want_val, _ = oracle.doh_maxima(cart, sig, 0.0005)
+    got_rcs, got_val = ctx.doh_maxima(cart, sig, 0.0005)
+    assert len(want_rcs) > 100
+    assert np.array_equal(got_rcs, want_rcs)
+    assert np.array_equal(got_val, want_val)
+    rng = np.random.default_rng(12)
+    for h, w in [(40, 50), (65, 64), (130, 97)]:
+        img = rng.random((h, w), dtype=np.float32)
+        for sg, thr in [([1.0, 2.0, 3.0], 0.001), ([0.01, 1.5], 0.0), ([2.0], 0.0005)]:
+            a, b, _ = oracle.doh_maxima(img, sg, thr)
+            c, d = ctx.doh_maxima(img, sg, thr)
+            assert np.array_equal(a, c) and np.array_equal(b, d), (h, w, sg)
+
+
+def test_get_features_matches_oracle(ctx, cart_pair):
+    from radarslampy_amd.getFeatures import getFeatures, appendNewFeatures, getBlobsFromCart, DEFAULT_FEATURE_PARAMS
+    cart = cart_pair[0][0]
+    blobs = getBlobsFromCart(cart, **DEFAULT_FEATURE_PARAMS)
+    want = oracle.blob_doh(cart.astype(np.float64), 0.01, 10, 3, 0.0005)
+    assert np.array_equal(blobs, want)
+    xy, rad = getFeatures(cart)
+    wxy, wrad = oracle.getFeatures(cart)
+    assert np.array_equal(xy, wxy) and np.array_equal(rad, wrad)
+    assert 180 <= len(xy) <= 220
+    old = xy[:50].astype(np.float32)
+    pts, thr = appendNewFeatures(cart, old)
+    assert thr == 80 and pts.dtype == np.float32
+    assert np.array_equal(pts, oracle.append_dedupe(old, wxy))
