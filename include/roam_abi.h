@@ -180,6 +180,10 @@ int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
 /* blocking: current feature set of a lane (cap rows), and its peak list */
 int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t lane, float *pts, int32_t cap, int32_t *K);
 int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_t cap, int64_t *n);
+/* a4 on a resident scan: DoH maxima of the float32 Cartesian warp of pool scan `pool_idx`
+ * (appendNewFeatures(currImgCart, ...) of RawROAMSystem.py:264 without moving image data) */
+int32_t roam_engine_doh_maxima(roam_ctx *ctx, int32_t pool_idx, const double *sigmas, int32_t num_sigma, double threshold,
+                               int32_t *out_rcs, double *out_val, int32_t cap, int32_t *n_out);
 /* blocking: level `level` (0..3) of the lane's most recent Cartesian u8 pyramid (w*h bytes, row-major) */
 int32_t roam_engine_lane_image(roam_ctx *ctx, int32_t lane, int32_t level, uint8_t *out, int64_t cap);
 /* replace a lane's feature set (retrack append, getFeatures.appendNewFeatures getFeatures.py:98-118) */

@@ -63,6 +63,7 @@ _SIGS = {
     "roam_engine_results": (C.c_int32, [_vp, _P(LaneResult), C.c_int32]),
     "roam_engine_lane_features": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_lane_peaks": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
+    "roam_engine_doh_maxima": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, C.c_double, _vp, _vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_lane_image": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.c_int64]),
     "roam_engine_set_features": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32]),
     "roam_engine_stage_times": (C.c_int32, [_vp, _vp, _P(C.c_char_p), C.c_int32, _P(C.c_int32)]),

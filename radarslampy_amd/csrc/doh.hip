@@ -163,26 +163,21 @@ __global__ __launch_bounds__(256) void doh_row_scan_kernel(const int32_t *__rest
     if (t == 0) *total_out = total;
 }
 
-extern "C" int32_t roam_doh_maxima(roam_ctx *ctx, const float *img, int32_t w, int32_t h, const double *sigmas,
-                                   int32_t num_sigma, double threshold, int32_t *out_rcs, double *out_val,
-                                   int32_t cap, int32_t *n_out)
+// device-side core: dimg (w x h f32, device) -> maxima copied to the host arrays
+static int32_t doh_maxima_device(roam_ctx *ctx, const float *dimg, int32_t w, int32_t h, const double *sigmas,
+                                 int32_t num_sigma, double threshold, int32_t *out_rcs, double *out_val,
+                                 int32_t cap, int32_t *n_out)
 {
-    if (!ctx) return ROAM_E_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ARG_CHECK(ctx, img && sigmas && out_rcs && out_val && n_out && w >= 3 && h >= 3 && num_sigma >= 1 &&
-                       num_sigma <= DOH_MAX_LAYERS && cap >= 0 && threshold >= 0);
     hipStream_t st = ctx->stream;
     const size_t npx = (size_t)w * h;
-    float *dimg = (float *)roam_scratch(ctx, S_IN0, sizeof(float) * npx);
     double *S = (double *)roam_scratch(ctx, S_TMP0, sizeof(double) * npx);
     int32_t *rowc = (int32_t *)roam_scratch(ctx, S_TMP1, sizeof(int32_t) * (2 * (size_t)h + 1));
     int32_t *drcs = (int32_t *)roam_scratch(ctx, S_OUT0, sizeof(int32_t) * 3 * (size_t)(cap > 0 ? cap : 1));
     double *dval = (double *)roam_scratch(ctx, S_OUT1, sizeof(double) * (size_t)(cap > 0 ? cap : 1));
-    if (!dimg || !S || !rowc || !drcs || !dval) return ROAM_E_HIP;
+    if (!S || !rowc || !drcs || !dval) return ROAM_E_HIP;
     static const int slots[DOH_MAX_LAYERS] = {S_TMP2, S_TMP3, S_TMP4, S_TMP5, S_TMP6, S_TMP7, S_IN2, S_IN3};
     DohLayers L;
     L.nl = num_sigma;
-    HIP_TRY(ctx, hipMemcpyAsync(dimg, img, sizeof(float) * npx, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(integ_cols_kernel, dim3((w + 255) / 256), dim3(256), 0, st, dimg, h, w, S);
     hipLaunchKernelGGL(integ_rows_kernel, dim3((h + 63) / 64), dim3(64), 0, st, S, h, w);
     HIP_TRY(ctx, hipGetLastError());
@@ -213,4 +208,35 @@ extern "C" int32_t roam_doh_maxima(roam_ctx *ctx, const float *img, int32_t w, i
     }
     if (n > cap) { ROAM_SET_ERR(ctx, "doh: %d maxima, capacity %d", n, cap); return ROAM_E_CAPACITY; }
     return ROAM_OK;
+}
+
+extern "C" int32_t roam_doh_maxima(roam_ctx *ctx, const float *img, int32_t w, int32_t h, const double *sigmas,
+                                   int32_t num_sigma, double threshold, int32_t *out_rcs, double *out_val,
+                                   int32_t cap, int32_t *n_out)
+{
+    if (!ctx) return ROAM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ARG_CHECK(ctx, img && sigmas && out_rcs && out_val && n_out && w >= 3 && h >= 3 && num_sigma >= 1 &&
+                       num_sigma <= DOH_MAX_LAYERS && cap >= 0 && threshold >= 0);
+    const size_t npx = (size_t)w * h;
+    float *dimg = (float *)roam_scratch(ctx, S_IN0, sizeof(float) * npx);
+    if (!dimg) return ROAM_E_HIP;
+    HIP_TRY(ctx, hipMemcpyAsync(dimg, img, sizeof(float) * npx, hipMemcpyHostToDevice, ctx->stream));
+    return doh_maxima_device(ctx, dimg, w, h, sigmas, num_sigma, threshold, out_rcs, out_val, cap, n_out);
+}
+
+// engine variant: the image is the float32 Cartesian warp of a raw record that is already resident
+// in HBM (`rec` = device pointer to rows x stride u8), i.e. appendNewFeatures(currImgCart, ...) of
+// RawROAMSystem.py:264 without any host round trip of image data.
+int32_t roam_doh_maxima_record_device(roam_ctx *ctx, const uint8_t *rec, int rows, int64_t stride, int payload_off,
+                                      int clip, const double *sigmas, int32_t num_sigma, double threshold,
+                                      int32_t *out_rcs, double *out_val, int32_t cap, int32_t *n_out)
+{
+    ARG_CHECK(ctx, rec && sigmas && out_rcs && out_val && n_out && num_sigma >= 1 && num_sigma <= DOH_MAX_LAYERS && cap >= 0);
+    const int W = 2 * (clip / 2);
+    float *dimg = (float *)roam_scratch(ctx, S_IN0, sizeof(float) * (size_t)W * W);
+    if (!dimg) return ROAM_E_HIP;
+    WarpSrc ws = {rec, 0, stride, payload_off, 1, nullptr};
+    HIP_TRY(ctx, launch_polar_to_cart(ctx->stream, ws, 1, rows, clip, nullptr, 0, dimg, (int64_t)W * W));
+    return doh_maxima_device(ctx, dimg, W, W, sigmas, num_sigma, threshold, out_rcs, out_val, cap, n_out);
 }

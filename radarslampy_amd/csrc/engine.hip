@@ -550,6 +550,16 @@ int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_
     return (n > cap || n > e->cfg.peaks_cap) ? ROAM_E_CAPACITY : ROAM_OK;
 }
 
+int32_t roam_engine_doh_maxima(roam_ctx *ctx, int32_t pool_idx, const double *sigmas, int32_t num_sigma, double threshold,
+                               int32_t *out_rcs, double *out_val, int32_t cap, int32_t *n_out)
+{
+    ENGINE();
+    ARG_CHECK(ctx, pool_idx >= 0 && pool_idx < e->cfg.pool_scans);
+    return roam_doh_maxima_record_device(ctx, e->pool + (size_t)pool_idx * e->rec_bytes, e->cfg.rows, e->cfg.stride,
+                                         e->cfg.payload_off, e->cfg.clip, sigmas, num_sigma, threshold, out_rcs, out_val,
+                                         cap, n_out);
+}
+
 int32_t roam_engine_lane_image(roam_ctx *ctx, int32_t lane, int32_t level, uint8_t *out, int64_t cap)
 {
     ENGINE();

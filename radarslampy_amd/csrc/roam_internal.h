@@ -138,3 +138,7 @@ hipError_t launch_mds_undistort(hipStream_t st, const double *v3, const double *
 
 hipError_t launch_ssc(hipStream_t st, const double *kp, int B, int num_ret, double tol, int cols,
                       int rows, int32_t *work, int32_t *sel, int32_t *n_sel);
+
+int32_t roam_doh_maxima_record_device(roam_ctx *ctx, const uint8_t *rec, int rows, int64_t stride, int payload_off,
+                                      int clip, const double *sigmas, int32_t num_sigma, double threshold,
+                                      int32_t *out_rcs, double *out_val, int32_t cap, int32_t *n_out);

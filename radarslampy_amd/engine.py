@@ -77,6 +77,33 @@ class Engine:
         self.ctx.check(self.lib.roam_engine_lane_peaks(self.ctx.h, int(lane), _ffi._ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def detect_features(self, pool_idx: int):
+        """getFeatures (getFeatures.py:74-95) on a resident scan: DoH maxima on the device, then the
+        blob_doh bookkeeping, SSC-ANMS (device) and the [x, y] flip."""
+        from . import getFeatures as gf
+        p = gf.DEFAULT_FEATURE_PARAMS
+        sig = np.linspace(p["min_sigma"], p["max_sigma"], p["num_sigma"])
+        cap = 1 << 18
+        rcs = np.empty((cap, 3), np.int32)
+        val = np.empty(cap, np.float64)
+        n = C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_doh_maxima(self.ctx.h, int(pool_idx), _ffi._ptr(sig), len(sig), float(p["threshold"]),
+                                                       _ffi._ptr(rcs), _ffi._ptr(val), cap, C.byref(n)))
+        blobs = gf.blobs_from_maxima(rcs[:n.value], val[:n.value], sig)
+        W = 2 * (self.cfg.clip // 2)
+        blobs = gf.adaptiveNMS(np.empty((W, W), np.bool_), blobs) if len(blobs) else blobs
+        return np.fliplr(blobs[:, :2])
+
+    def retrack_lane(self, lane: int, pool_idx: int):
+        """appendNewFeatures(currImgCart, good_new) + keyframe refresh (RawROAMSystem.py:264-270)."""
+        from . import getFeatures as gf
+        new = self.detect_features(pool_idx)
+        pts = gf.dedupe_append(self.lane_features(lane), new)
+        if len(pts) > _ffi.MAX_FEATURES:
+            pts = pts[:_ffi.MAX_FEATURES]
+        self.set_features(lane, pts)
+        return pts
+
     def lane_image(self, lane: int, level: int = 0):
         W = 2 * (self.cfg.clip // 2)
         for _ in range(level):

@@ -73,6 +73,11 @@ def getBlobsFromCart(cartImage: np.ndarray, min_sigma=1, max_sigma=30, num_sigma
         raise NotImplementedError(f"{method} not implemented! Use 'doh'")
     sigma_list = np.linspace(min_sigma, max_sigma, num_sigma)
     rcs, val = _ffi.default_context().doh_maxima(cartImage, sigma_list, threshold)
+    return blobs_from_maxima(rcs, val, sigma_list, overlap)
+
+
+def blobs_from_maxima(rcs, val, sigma_list, overlap=0.5):
+    """host bookkeeping of blob_doh after the image-scale work: response order, sigma lookup, pruning"""
     if len(rcs) == 0:
         return np.empty((0, 3))
     idx = np.argsort(-val)                        # peak_local_max: highest response first

@@ -70,3 +70,33 @@ def test_engine_argument_errors():
         eng.init_lane(3, 0, np.zeros((4, 2), np.float32), np.zeros(3))
     eng.close()
     ctx.close()
+
+
+def test_engine_retrack_matches_oracle(sequences):
+    """Few initial features -> the retrack branch (RawROAMSystem.py:250-271): DoH + SSC-ANMS on the
+    resident scan, dedupe-append, keyframe refresh; then tracking continues from the new set."""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = sequences[0]
+    T = len(recs)
+    ctx = _ffi.Context(0)
+    eng = Engine(1, T, ctx=ctx)
+    for t in range(T):
+        eng.upload_scan(t, recs[t])
+    feat0 = feat[:64]
+    eng.init_lane(0, 0, feat0, poses[0])
+    pipe = oracle.OdometryPipeline(recs[0], feat0, poses[0], detect=lambda cart: oracle.getFeatures(cart)[0])
+    saw_retrack = False
+    for t in range(1, T):
+        eng.step([t])
+        got = eng.results()[0]
+        want = pipe.step(recs[t])
+        assert got["retrack"] == bool(want["retrack"]) and got["n_inliers"] == want["n_inliers"], t
+        if got["retrack"]:
+            saw_retrack = True
+            eng.retrack_lane(0, t)
+        assert np.array_equal(eng.lane_features(0), pipe.blobCoord), t
+        assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= POS_TOL and abs(got["pose"][2] - want["pose"][2]) <= ANG_TOL, t
+    assert saw_retrack and len(pipe.blobCoord) > 150
+    eng.close()
+    ctx.close()
