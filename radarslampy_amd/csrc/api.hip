@@ -22,6 +22,7 @@ int32_t roam_create(int32_t device_id, roam_ctx **out)
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
     ctx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
     *out = ctx;
     return ROAM_OK;
 }
@@ -35,6 +36,8 @@ int32_t roam_destroy(roam_ctx *ctx)
     roam_engine_destroy(ctx);
     hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->scratch) if (s.p) hipFree(s.p);
+    hipStreamSynchronize(ctx->stream2);
+    hipStreamDestroy(ctx->stream2);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return ROAM_OK;

@@ -58,6 +58,7 @@ struct Engine {
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
     roam_lane_result *results = nullptr;
     hipEvent_t ev[ST_COUNT + 1];
+    hipEvent_t ev_fork, ev_join, ev_pk0, ev_pk1;   // side-stream fork / join + its own timing pair
     bool ev_ok = false, stepped = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
     int kmax() const { int m = 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
@@ -309,7 +310,8 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (void *p : e->allocs) hipFree(p);
-    if (e->ev_ok) for (auto &ev : e->ev) hipEventDestroy(ev);
+    if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1); }
+    hipStreamSynchronize(ctx->stream2);
     delete e;
     ctx->engine = nullptr;
     return ROAM_OK;
@@ -380,6 +382,10 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     if (!ok) { roam_engine_destroy(ctx); return ROAM_E_HIP; }
     for (auto &ev : e->ev) {
         if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    }
+    if (hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess ||
+        hipEventCreate(&e->ev_pk0) != hipSuccess || hipEventCreate(&e->ev_pk1) != hipSuccess) {
+        ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
     e->ev_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
@@ -459,9 +465,17 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx, scan_idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, st));
     uint8_t *prev = e->pyr[e->cur], *next = e->pyr[e->cur ^ 1];
 
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], st));
+    // polar peaks (a2) depend only on the raw scan: they run on the side stream, concurrently with
+    // the warp -> pyramid -> KLT -> ... chain, and are joined before the per-lane result record
+    hipStream_t s2 = ctx->stream2;
+    HIP_TRY(ctx, hipEventRecord(e->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(s2, e->ev_fork, 0));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, s2));
     PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};
-    HIP_TRY(ctx, launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n));
+    HIP_TRY(ctx, launch_peaks(s2, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, s2));
+    HIP_TRY(ctx, hipEventRecord(e->ev_join, s2));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], st));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], st));
     HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], st));
@@ -497,6 +511,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
                        e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n,
                        e->cq_flags, e->results);
@@ -580,7 +595,8 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev_pk0, e->ev_pk1));   // side stream (overlapped)
+        else HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
         ms_out[i] = ms;
         if (names_out) names_out[i] = kStageNames[i];
     }

@@ -65,60 +65,50 @@ __device__ __forceinline__ float np_leaf_sum(const float *a, int n)
     return res;
 }
 
-struct PwShared {
-    int leaf_lo[64];
-    int leaf_n[64];
-    float leaf_sum[64];
-    int stk_lo[12], stk_n[12], stk_state[12];
-    float stk_lv[12];
-    int nleaf;
-    float result;
+// NumPy's recursion for length n: split at n2 = n/2 - (n/2)%8 while n > 128.  The recursion is
+// unrolled at compile time (depth <= 6 covers n <= 8192); n is block-uniform, so the whole walk
+// is scalar work that every thread repeats for itself - no LDS stack, no serial thread-0 section
+// (the first version kept an explicit stack in LDS: ~12 us of dependent LDS latency per row).
+template <int D>
+struct PwWalk {
+    // leaf number `target` of the in-order leaf sequence -> (my_lo, my_n)
+    static __device__ __forceinline__ void select(int lo, int n, int target, int &cnt, int &my_lo, int &my_n)
+    {
+        if (n <= 128) { if (cnt == target) { my_lo = lo; my_n = n; } cnt++; return; }
+        int n2 = n / 2; n2 -= n2 % 8;
+        PwWalk<D - 1>::select(lo, n2, target, cnt, my_lo, my_n);
+        PwWalk<D - 1>::select(lo + n2, n - n2, target, cnt, my_lo, my_n);
+    }
+    static __device__ __forceinline__ float combine(const float *leaf_sum, int n, int &li)
+    {
+        if (n <= 128) return leaf_sum[li++];
+        int n2 = n / 2; n2 -= n2 % 8;
+        const float a = PwWalk<D - 1>::combine(leaf_sum, n2, li);
+        const float b = PwWalk<D - 1>::combine(leaf_sum, n - n2, li);
+        return __fadd_rn(a, b);
+    }
+};
+template <>
+struct PwWalk<0> {
+    static __device__ __forceinline__ void select(int lo, int n, int target, int &cnt, int &my_lo, int &my_n)
+    {
+        if (cnt == target) { my_lo = lo; my_n = n; }
+        cnt++;
+    }
+    static __device__ __forceinline__ float combine(const float *leaf_sum, int, int &li) { return leaf_sum[li++]; }
 };
 
-// enumerate the leaves of NumPy's recursion for length n (thread 0), in order
-__device__ void pw_enumerate(PwShared *s, int n)
+// block-wide NumPy-ordered float32 sum of a[0..n) (a and leaf_sum in LDS); every thread gets the result
+__device__ __forceinline__ float block_np_sum(float *leaf_sum, const float *a, int n)
 {
-    int sp = 0, nl = 0;
-    s->stk_lo[0] = 0; s->stk_n[0] = n; s->stk_state[0] = 0;
-    while (sp >= 0) {
-        int cn = s->stk_n[sp], lo = s->stk_lo[sp];
-        if (cn <= 128) { s->leaf_lo[nl] = lo; s->leaf_n[nl] = cn; nl++; sp--; continue; }
-        int n2 = cn / 2; n2 -= n2 % 8;
-        int stt = s->stk_state[sp];
-        if (stt == 0) { s->stk_state[sp] = 1; s->stk_lo[sp + 1] = lo; s->stk_n[sp + 1] = n2; s->stk_state[sp + 1] = 0; sp++; }
-        else if (stt == 1) { s->stk_state[sp] = 2; s->stk_lo[sp + 1] = lo + n2; s->stk_n[sp + 1] = cn - n2; s->stk_state[sp + 1] = 0; sp++; }
-        else sp--;
-    }
-    s->nleaf = nl;
-}
-
-// combine leaf sums in recursion order (thread 0)
-__device__ float pw_combine(PwShared *s, int n)
-{
-    int sp = 0, li = 0;
-    float ret = 0.f;
-    s->stk_n[0] = n; s->stk_state[0] = 0;
-    while (sp >= 0) {
-        int cn = s->stk_n[sp];
-        if (cn <= 128) { ret = s->leaf_sum[li++]; sp--; continue; }
-        int n2 = cn / 2; n2 -= n2 % 8;
-        int stt = s->stk_state[sp];
-        if (stt == 0) { s->stk_state[sp] = 1; s->stk_n[sp + 1] = n2; s->stk_state[sp + 1] = 0; sp++; }
-        else if (stt == 1) { s->stk_lv[sp] = ret; s->stk_state[sp] = 2; s->stk_n[sp + 1] = cn - n2; s->stk_state[sp + 1] = 0; sp++; }
-        else { ret = __fadd_rn(s->stk_lv[sp], ret); sp--; }
-    }
-    return ret;
-}
-
-// block-wide NumPy-ordered float32 sum of a[0..n) (a in LDS); leaves must be enumerated
-__device__ float block_np_sum(PwShared *s, const float *a, int n)
-{
-    const int t = threadIdx.x;
-    if (t < s->nleaf) s->leaf_sum[t] = np_leaf_sum(a + s->leaf_lo[t], s->leaf_n[t]);
+    int cnt = 0, my_lo = 0, my_n = -1;
+    PwWalk<6>::select(0, n, (int)threadIdx.x, cnt, my_lo, my_n);
+    if (my_n >= 0) leaf_sum[threadIdx.x] = np_leaf_sum(a + my_lo, my_n);
     __syncthreads();
-    if (t == 0) s->result = pw_combine(s, n);
+    int li = 0;
+    const float r = PwWalk<6>::combine(leaf_sum, n, li);
     __syncthreads();
-    return s->result;
+    return r;
 }
 
 template <bool U8>
@@ -127,7 +117,7 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
                                                           int32_t *__restrict__ row_count)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ PwShared pw;
+    __shared__ float leaf_sum[PK_T];
     __shared__ int scan_sh[8];
     const int half = (cols + 1) / 2;
     float *xs = reinterpret_cast<float *>(smem_raw);          // cols
@@ -176,20 +166,19 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
             }
         }
     }
+    __syncthreads();                   // ph / pm complete before the leaf sums read them
     if (M == 0) {                      // numpy: mean of empty = NaN -> nothing passes
         if (t == 0) row_count[b * rows + r] = 0;
         return;
     }
-    if (t == 0) pw_enumerate(&pw, M);
-    __syncthreads();
     const float fM = (float)M;
-    const float mean = __fdiv_rn(block_np_sum(&pw, ph, M), fM);
+    const float mean = __fdiv_rn(block_np_sum(leaf_sum, ph, M), fM);
     for (int k = t; k < M; k += PK_T) {
         float d = __fsub_rn(ph[k], mean);
         sq[k] = __fmul_rn(d, d);
     }
     __syncthreads();
-    const float var = __fdiv_rn(block_np_sum(&pw, sq, M), fM);
+    const float var = __fdiv_rn(block_np_sum(leaf_sum, sq, M), fM);
     const float thr = __fadd_rn(mean, rn_sqrtf(var));
 
     // ---- threshold + ordered compaction

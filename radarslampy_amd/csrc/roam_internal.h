@@ -25,6 +25,7 @@ struct Engine;
 struct roam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // side stream: work that is independent of the tracking chain (polar peaks)
     char err[512] = {0};
     // growable scratch buffers for the stage API (indexed by role)
     DevBuf scratch[24];
