@@ -16,7 +16,7 @@
 
 #define EPSMCH 2.220446049250313e-16
 #define DWARF 2.2250738585072014e-308
-#define LM_T 256
+#define LM_TMAX 256
 #define TWO_PI 6.283185307179586476925286766559
 
 __device__ __forceinline__ double wave_sum_d(double v)
@@ -116,7 +116,7 @@ __device__ void mds_resid(const LmShared *S, const double *x, const double *p_w,
     const int N = S->N;
     const double th = x[5], tx = x[3], ty = x[4];
     const double ct = cos(th), st = sin(th);
-    for (int i = threadIdx.x; i < N; i += LM_T) {
+    for (int i = threadIdx.x; i < N; i += (int)blockDim.x) {
         const double d = dT[i];
         const double a = x[2] * d, ddx = x[0] * d, ddy = x[1] * d;
         const double ca = cos(a), sa = sin(a);
@@ -271,7 +271,7 @@ __device__ void lmpar6(int m, double *a, const int *ipvt, const double *diag, co
 
 #define LM_LDS_BYTES 65536
 
-__global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
+__global__ __launch_bounds__(LM_TMAX) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
                                                       double *__restrict__ out6, int32_t *__restrict__ nfev_out,
                                                       int32_t *__restrict__ info_out, double *__restrict__ x0_out,
                                                       double *__restrict__ r0_out)
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
         for (int j = 0; j < 6; j++) S.diag[j] = 1.0;
         S.info = 0; S.nfev = 1; S.iter = 1; S.par = 0; S.delta = 0; S.xnorm = 0; S.gnorm = 0;
     }
-    for (int i = t; i < N; i += LM_T) dT[i] = P.period * atan2(-p_jt[2 * i + 1], -p_jt[2 * i]) / TWO_PI;
+    for (int i = t; i < N; i += (int)blockDim.x) dT[i] = P.period * atan2(-p_jt[2 * i + 1], -p_jt[2 * i]) / TWO_PI;
     __syncthreads();
     double xl[6];
 #pragma unroll
@@ -317,10 +317,10 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
     mds_resid(&S, xl, p_w, p_jt, dT, fvec);
     __syncthreads();
     if (x0_out && t < 6) x0_out[(size_t)b * 6 + t] = S.x[t];
-    if (r0_out) for (int i = t; i < m; i += LM_T) r0_out[(size_t)b * mmax + i] = fvec[i];
+    if (r0_out) for (int i = t; i < m; i += (int)blockDim.x) r0_out[(size_t)b * mmax + i] = fvec[i];
     {
         double s = 0;
-        for (int i = t; i < m; i += LM_T) s += fvec[i] * fvec[i];
+        for (int i = t; i < m; i += (int)blockDim.x) s += fvec[i] * fvec[i];
         s = block_sum_d(s, red);
         if (t == 0) S.fnorm = sqrt(s);
         __syncthreads();
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
             xl[j] = temp + h;
             mds_resid(&S, xl, p_w, p_jt, dT, wf);
             xl[j] = temp;
-            for (int i = t; i < N; i += LM_T) {
+            for (int i = t; i < N; i += (int)blockDim.x) {
                 A_(2 * i, j) = (wf[2 * i] - fvec[2 * i]) / h;
                 A_(2 * i + 1, j) = (wf[2 * i + 1] - fvec[2 * i + 1]) / h;
             }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
         // ---- qrfac with column pivoting
         for (int j = 0; j < n; j++) {
             double s = 0;
-            for (int i = t; i < m; i += LM_T) s += A_(i, j) * A_(i, j);
+            for (int i = t; i < m; i += (int)blockDim.x) s += A_(i, j) * A_(i, j);
             s = block_sum_d(s, red);
             if (t == 0) { S.wa2[j] = sqrt(s); S.wa1[j] = S.wa2[j]; S.wa3[j] = S.wa2[j]; S.ipvt[j] = j; }
         }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
             for (int k = j; k < n; k++) if (S.wa1[k] > S.wa1[kmax]) kmax = k;
             __syncthreads();
             if (kmax != j) {
-                for (int i = t; i < m; i += LM_T) { double tmp = A_(i, j); A_(i, j) = A_(i, kmax); A_(i, kmax) = tmp; }
+                for (int i = t; i < m; i += (int)blockDim.x) { double tmp = A_(i, j); A_(i, j) = A_(i, kmax); A_(i, kmax) = tmp; }
                 if (t == 0) {
                     S.wa1[kmax] = S.wa1[j]; S.wa3[kmax] = S.wa3[j];
                     int tp = S.ipvt[j]; S.ipvt[j] = S.ipvt[kmax]; S.ipvt[kmax] = tp;
@@ -368,23 +368,23 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
                 __syncthreads();
             }
             double s = 0;
-            for (int i = j + t; i < m; i += LM_T) s += A_(i, j) * A_(i, j);
+            for (int i = j + t; i < m; i += (int)blockDim.x) s += A_(i, j) * A_(i, j);
             s = block_sum_d(s, red);
             double ajnorm = sqrt(s);
             if (ajnorm != 0) {
                 if (A_(j, j) < 0) ajnorm = -ajnorm;
                 __syncthreads();
-                for (int i = j + t; i < m; i += LM_T) A_(i, j) /= ajnorm;
+                for (int i = j + t; i < m; i += (int)blockDim.x) A_(i, j) /= ajnorm;
                 __syncthreads();
                 if (t == 0) A_(j, j) += 1;
                 __syncthreads();
                 for (int k = j + 1; k < n; k++) {
                     double sum = 0;
-                    for (int i = j + t; i < m; i += LM_T) sum += A_(i, j) * A_(i, k);
+                    for (int i = j + t; i < m; i += (int)blockDim.x) sum += A_(i, j) * A_(i, k);
                     sum = block_sum_d(sum, red);
                     const double temp = sum / A_(j, j);
                     __syncthreads();
-                    for (int i = j + t; i < m; i += LM_T) A_(i, k) -= temp * A_(i, j);
+                    for (int i = j + t; i < m; i += (int)blockDim.x) A_(i, k) -= temp * A_(i, j);
                     __syncthreads();
                     // rdiag down-date (uniform decisions from shared values)
                     double rk = S.wa1[k];
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
                     }
                     double s2 = 0;
                     if (recompute) {
-                        for (int i = j + 1 + t; i < m; i += LM_T) s2 += A_(i, k) * A_(i, k);
+                        for (int i = j + 1 + t; i < m; i += (int)blockDim.x) s2 += A_(i, k) * A_(i, k);
                         s2 = block_sum_d(s2, red);
                         rk = sqrt(s2);
                     }
@@ -417,17 +417,17 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
             if (S.delta == 0) S.delta = 100.0;
         }
         // ---- Q^T fvec -> qtf
-        for (int i = t; i < m; i += LM_T) wa4[i] = fvec[i];
+        for (int i = t; i < m; i += (int)blockDim.x) wa4[i] = fvec[i];
         __syncthreads();
         for (int j = 0; j < n; j++) {
             const double ajj = A_(j, j);
             if (ajj != 0) {
                 double sum = 0;
-                for (int i = j + t; i < m; i += LM_T) sum += A_(i, j) * wa4[i];
+                for (int i = j + t; i < m; i += (int)blockDim.x) sum += A_(i, j) * wa4[i];
                 sum = block_sum_d(sum, red);
                 const double temp = -sum / ajj;
                 __syncthreads();
-                for (int i = j + t; i < m; i += LM_T) wa4[i] += A_(i, j) * temp;
+                for (int i = j + t; i < m; i += (int)blockDim.x) wa4[i] += A_(i, j) * temp;
             }
             __syncthreads();
             if (t == 0) { A_(j, j) = S.wa1[j]; S.qtf[j] = wa4[j]; }
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
             mds_resid(&S, xl, p_w, p_jt, dT, wa4);
             __syncthreads();
             double s = 0;
-            for (int i = t; i < m; i += LM_T) s += wa4[i] * wa4[i];
+            for (int i = t; i < m; i += (int)blockDim.x) s += wa4[i] * wa4[i];
             s = block_sum_d(s, red);
             if (t == 0) {
                 S.nfev++;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(LM_T) void mds_lm_kernel(MdsProblemDesc P, double *
                 S.ratio = ratio;
             }
             __syncthreads();
-            if (S.accept) for (int i = t; i < m; i += LM_T) fvec[i] = wa4[i];
+            if (S.accept) for (int i = t; i < m; i += (int)blockDim.x) fvec[i] = wa4[i];
             const int info = S.info;
             const double ratio = S.ratio;
             __syncthreads();
@@ -540,7 +540,10 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     const size_t mmax = 2 * (size_t)p.nmax + 3;
     size_t need = (mmax * 9 + p.nmax) * sizeof(double);
     size_t lds = need <= LM_LDS_BYTES ? need : 0;
-    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(LM_T), lds, st, p, work, out6, nfev, info, x0_out, r0_out);
+    // the solve is a long chain of short reductions: with few points a single wavefront per problem
+    // (workgroup barriers degenerate to no-ops, reductions stay in registers) has the lowest latency
+    const int threads = p.nmax <= 192 ? 64 : (p.nmax <= 448 ? 128 : LM_TMAX);
+    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out);
     return hipGetLastError();
 }
 

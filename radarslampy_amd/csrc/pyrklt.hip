@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
 {
     __shared__ short It[18][18];
     __shared__ short Dx[16][16], Dy[16][16];
-    __shared__ short Jt[16][17];
+    __shared__ short Jt[32][33];          // cached 32x32 neighbourhood of the next image (reloaded only when the window leaves it)
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     if (count && k >= count[b]) return;
     const int64_t pidx = ((int64_t)b * kstride + k) * 2;
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
         D = __fdiv_rn(1.f, D);
         nx = __fsub_rn(nx, halfWin); ny = __fsub_rn(ny, halfWin);
         float pdx = 0.f, pdy = 0.f;
+        int tx0 = -(1 << 28), ty0 = -(1 << 28);            // cached tile origin (invalid)
         for (int j = 0; j < 10; j++) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -KW || inx >= w || iny < -KW || iny >= h) {
@@ -364,19 +365,21 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                 break;
             }
             bilin_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny), iw00, iw01, iw10, iw11);
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int i = lane + 64 * q;
-                int y = i >> 4, x = i & 15;
-                Jt[y][x] = (short)J[(int64_t)reflect101(iny + y, h) * w + reflect101(inx + x, w)];
+            if (!(inx >= tx0 && inx - tx0 <= 15 && iny >= ty0 && iny - ty0 <= 15)) {
+                tx0 = inx - 8; ty0 = iny - 8;
+                __syncthreads();
+                for (int i = lane; i < 32 * 32; i += 64) {
+                    int y = i >> 5, x = i & 31;
+                    Jt[y][x] = (short)J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            const int jox = inx - tx0, joy = iny - ty0;
             long long sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (lane + 64 * q < KW * KW) {
-                    int y = py_[q], x = px_[q];
+                    int y = joy + py_[q], x = jox + px_[q];
                     int jv = DESCALE(Jt[y][x] * iw00 + Jt[y][x + 1] * iw01 + Jt[y + 1][x] * iw10 + Jt[y + 1][x + 1] * iw11, W_BITS - 5);
                     int diff = jv - Iv[q];
                     sb1 += (long long)diff * Ix[q];
@@ -402,19 +405,21 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
             const int iex = (int)floorf(ex), iey = (int)floorf(ey);
             if (iex < -KW || iex >= w || iey < -KW || iey >= h) { st = 0; continue; }
             bilin_weights(__fsub_rn(ex, (float)iex), __fsub_rn(ey, (float)iey), iw00, iw01, iw10, iw11);
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                int i = lane + 64 * q;
-                int y = i >> 4, x = i & 15;
-                Jt[y][x] = (short)J[(int64_t)reflect101(iey + y, h) * w + reflect101(iex + x, w)];
+            if (!(iex >= tx0 && iex - tx0 <= 15 && iey >= ty0 && iey - ty0 <= 15)) {
+                tx0 = iex - 8; ty0 = iey - 8;
+                __syncthreads();
+                for (int i = lane; i < 32 * 32; i += 64) {
+                    int y = i >> 5, x = i & 31;
+                    Jt[y][x] = (short)J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            const int eox = iex - tx0, eoy = iey - ty0;
             long long se = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (lane + 64 * q < KW * KW) {
-                    int y = py_[q], x = px_[q];
+                    int y = eoy + py_[q], x = eox + px_[q];
                     int jv = DESCALE(Jt[y][x] * iw00 + Jt[y][x + 1] * iw01 + Jt[y + 1][x] * iw10 + Jt[y + 1][x + 1] * iw11, W_BITS - 5);
                     int diff = jv - Iv[q];
                     se += diff < 0 ? -diff : diff;
