@@ -29,10 +29,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=64, help="independent sequences resident per GPU")
+    ap.add_argument("--lanes", type=int, default=1024, help="independent sequences resident per GPU")
     ap.add_argument("--frames", type=int, default=7, help="frames per synthetic sequence (played ping-pong)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences generated per rank")
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="scan pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
     ap.add_argument("--kernel-reps", type=int, default=10)
     args = ap.parse_args()
@@ -45,7 +45,11 @@ def main():
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        except Exception as e:                                                                  # plumbing only: fall back to gloo
+            sys.stderr.write(f"[bench] nccl init failed ({e}); using gloo for the barrier/reduction\n")
+            dist_mod.init_process_group("gloo")
         dist = dist_mod
 
     from radarslampy_amd import _ffi, synth
@@ -54,7 +58,7 @@ def main():
     ctx = _ffi.Context(local_rank)
     info = ctx.device_info()
     B, T, D = args.lanes, args.frames, max(1, min(args.distinct, args.lanes))
-    seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, n_movers=16, distortion=not args.no_md) for d in range(D)]
+    seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, n_static=460, n_movers=24, distortion=not args.no_md) for d in range(D)]
     eng = Engine(B, D * T, ctx=ctx, motion_distortion=not args.no_md)
     for d, (recs, poses, feat) in enumerate(seqs):
         for t in range(T):
@@ -89,7 +93,7 @@ def main():
     stages = eng.stage_times()
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], device="cuda")
+        tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -97,16 +101,17 @@ def main():
     if rank == 0:
         pairs = B * args.steps * world
         value = pairs / dt
-        # ---- roofline of the dominant kernel (HIP events on the kernel's own stream)
-        streaming = {k: stages[k] for k in ("ingest_peaks", "warp_quantise", "pyramid")}
-        dom_stage = max(stages, key=stages.get)
-        dom_stream = max(streaming, key=streaming.get)
-        ms, algo_bytes = eng.time_kernel(dom_stream, args.kernel_reps)
+        # ---- roofline of the dominant HBM-streaming kernel: each candidate is re-launched over all lanes
+        # in isolation and timed with HIP events on the engine's own stream (roam_engine_time_kernel)
+        iso = {k: eng.time_kernel(k, args.kernel_reps) for k in ("ingest_peaks", "warp_quantise", "pyramid")}
+        dom_stream = max(iso, key=lambda k: iso[k][0])
+        ms, algo_bytes = iso[dom_stream]
         achieved = algo_bytes / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom_stream, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                    "dominant_stage_of_step": dom_stage}
+                    "isolated_kernel_ms": {k: round(v[0], 4) for k, v in iso.items()},
+                    "isolated_kernel_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in iso.items()}}
         # whole-path view: SURVEY 8d B_min = 13.07 MB per steady pair
         path_gbs = 13.07e6 * (value / world) / 1e9
         cpu = None
@@ -129,6 +134,7 @@ def main():
             "config": {"workload": "steady-state scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
                                    + ("motion-distortion LM" if not args.no_md else "dead reckoning") + ")",
                        "lanes_per_gpu": B, "frames": T, "device": info["name"], "arch": info["arch"],
+                       "initial_features": int(np.mean([len(q[2]) for q in seqs])),
                        "mean_tracked": round(float(np.mean([r["n_tracked"] for r in res])), 1),
                        "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
                        "stage_ms_last_step": {k: round(v, 4) for k, v in stages.items()},
