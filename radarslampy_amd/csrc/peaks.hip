@@ -18,6 +18,9 @@
 #include "roam_internal.h"
 
 #define PK_T 256
+#define XI(i) (i)
+// (float)k / 255.f for a power code k, exactly (see tests/test_abi_cpu.py::test_u8_decode_identity)
+__device__ __forceinline__ float code_to_f32_pk(uint32_t k) { return (float)__dmul_rn((double)k, 1.0 / 255.0); }
 
 __device__ __forceinline__ int block_excl_scan(int v, int *sh, int *total)
 {
@@ -130,11 +133,11 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
     if (U8) {
         const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
                            (int64_t)r * src.row_stride + src.payload_off;
-        for (int i = t; i < cols; i += PK_T) xs[i] = (float)__dmul_rn((double)p[i], 1.0 / 255.0);   // == (float)k/255.f for all 256 codes
+        for (int i = t; i < cols; i += PK_T) xs[XI(i)] = (float)__dmul_rn((double)p[i], 1.0 / 255.0);   // == (float)k/255.f for all 256 codes
     } else {
         const float *p = reinterpret_cast<const float *>(src.base) + lane_sel * src.lane_stride +
                          (int64_t)r * src.row_stride;
-        for (int i = t; i < cols; i += PK_T) xs[i] = p[i];
+        for (int i = t; i < cols; i += PK_T) xs[XI(i)] = p[i];
     }
     __syncthreads();
 
@@ -144,23 +147,23 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
     const int imax = cols - 1;
     int cnt = 0;
     for (int i = max(lo, 1); i < hi && i < imax; i++) {
-        float v = xs[i];
-        if (xs[i - 1] < v) {
+        float v = xs[XI(i)];
+        if (xs[XI(i - 1)] < v) {
             int ia = i + 1;
-            while (ia < imax && xs[ia] == v) ia++;
-            if (xs[ia] < v) cnt++;
+            while (ia < imax && xs[XI(ia)] == v) ia++;
+            if (xs[XI(ia)] < v) cnt++;
         }
     }
     int M;
     int pos = block_excl_scan(cnt, scan_sh, &M);
     for (int i = max(lo, 1); i < hi && i < imax; i++) {
-        float v = xs[i];
-        if (xs[i - 1] < v) {
+        float v = xs[XI(i)];
+        if (xs[XI(i - 1)] < v) {
             int ia = i + 1;
-            while (ia < imax && xs[ia] == v) ia++;
-            if (xs[ia] < v) {
+            while (ia < imax && xs[XI(ia)] == v) ia++;
+            if (xs[XI(ia)] < v) {
                 int mid = (i + ia - 1) >> 1;
-                ph[pos] = xs[mid];
+                ph[pos] = xs[XI(mid)];
                 pm[pos] = (uint16_t)mid;
                 pos++;
             }
@@ -194,6 +197,118 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
             if (p2 < stage_cap) dst[p2] = pm[k];
             p2++;
         }
+    if (t == 0) row_count[b * rows + r] = total;
+}
+
+// ---- specialised row kernel for the live configuration: u8 record rows, cols <= 2048 -----------
+// One thread per 8 consecutive range bins, the 8 power codes stay in registers (the u8 -> float32
+// map k -> k/255 is strictly increasing, so maxima / plateaus are found on the integer codes and
+// only the surviving candidates are converted), neighbours come from an LDS byte copy of the row,
+// NumPy-order leaf sums use 8 lanes per leaf (one per accumulator, combined by a 3-step butterfly
+// that reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) exactly), at most 4 candidates per thread.
+#define PKF_MAXC 2048
+__global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int rows, int cols,
+                                                             uint16_t *__restrict__ row_stage, int stage_cap,
+                                                             int32_t *__restrict__ row_count)
+{
+    __shared__ __align__(16) uint8_t xb[PKF_MAXC + 16];
+    __shared__ float ph[PKF_MAXC / 2], sq[PKF_MAXC / 2];
+    __shared__ uint16_t pm[PKF_MAXC / 2];
+    __shared__ float leaf_sum[PK_T / 8];
+    __shared__ int scan_sh[8];
+    const int b = blockIdx.y, r = blockIdx.x, t = threadIdx.x;
+    const int64_t lane_sel = src.lane_index ? (int64_t)src.lane_index[b] : (int64_t)b;
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
+                       (int64_t)r * src.row_stride + src.payload_off;
+    const int base = t * 8;
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (base + j < cols) ? (uint32_t)p[base + j] : 0u;
+    {
+        const uint32_t w0 = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        const uint32_t w1 = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+        *reinterpret_cast<uint2 *>(&xb[base]) = make_uint2(w0, w1);
+    }
+    __syncthreads();
+    const int imax = cols - 1;
+    const uint32_t prev = (base > 0) ? (uint32_t)xb[base - 1] : 0u;
+
+    // candidate test for element j of this thread's chunk; returns the plateau midpoint or -1
+    auto peak_mid = [&](int j) -> int {
+        const int i = base + j;
+        if (i < 1 || i >= imax) return -1;
+        const uint32_t c = v[j];
+        const uint32_t left = (j > 0) ? v[j > 0 ? j - 1 : 0] : prev;
+        if (!(left < c)) return -1;
+        const uint32_t nxt = (j < 7) ? v[j < 7 ? j + 1 : 7] : (uint32_t)xb[i + 1];
+        if (nxt < c) return i;
+        if (nxt > c) return -1;
+        int ia = i + 1;                               // plateau: walk the LDS copy
+        while (ia < imax && (uint32_t)xb[ia] == c) ia++;
+        return ((uint32_t)xb[ia] < c) ? ((i + ia - 1) >> 1) : -1;
+    };
+    int mids[8];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { mids[j] = peak_mid(j); cnt += mids[j] >= 0; }
+    int M;
+    int pos = block_excl_scan(cnt, scan_sh, &M);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (mids[j] >= 0) { ph[pos] = code_to_f32_pk(v[j]); pm[pos] = (uint16_t)mids[j]; pos++; }
+    __syncthreads();
+    if (M == 0) {
+        if (t == 0) row_count[b * rows + r] = 0;
+        return;
+    }
+    // NumPy pairwise sum with 8 lanes per leaf
+    auto np_sum = [&](const float *a) -> float {
+        int lcnt = 0, my_lo = 0, my_n = -1;
+        PwWalk<4>::select(0, M, t >> 3, lcnt, my_lo, my_n);
+        const int j = t & 7;
+        float res = 0.f;
+        if (my_n >= 8) {
+            float rj = a[my_lo + j];
+            const int nn = my_n - (my_n & 7);
+            for (int i = 8; i < nn; i += 8) rj = __fadd_rn(rj, a[my_lo + i + j]);
+            rj = __fadd_rn(rj, __shfl_xor(rj, 1));
+            rj = __fadd_rn(rj, __shfl_xor(rj, 2));
+            rj = __fadd_rn(rj, __shfl_xor(rj, 4));
+            res = rj;
+            if (j == 0) for (int i = nn; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);
+        } else if (my_n >= 0) {
+            // short leaf (only when M < 8): sequential from 0
+            if (j == 0) for (int i = 0; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);
+            // keep the shuffles convergent
+            (void)__shfl_xor(res, 1);
+        }
+        if (my_n >= 0 && j == 0) leaf_sum[t >> 3] = res;
+        __syncthreads();
+        int li = 0;
+        const float tot = PwWalk<4>::combine(leaf_sum, M, li);
+        __syncthreads();
+        return tot;
+    };
+    const float fM = (float)M;
+    const float mean = __fdiv_rn(np_sum(ph), fM);
+    for (int k = t; k < M; k += PK_T) {
+        float d = __fsub_rn(ph[k], mean);
+        sq[k] = __fmul_rn(d, d);
+    }
+    __syncthreads();
+    const float var = __fdiv_rn(np_sum(sq), fM);
+    const float thr = __fadd_rn(mean, rn_sqrtf(var));
+    // threshold + ordered compaction: 4 consecutive candidates per thread (M <= 1024)
+    int c2 = 0;
+    bool keep[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int k = t * 4 + q; keep[q] = (k < M) && (ph[k] >= thr); c2 += keep[q]; }
+    int total;
+    int p2 = block_excl_scan(c2, scan_sh, &total);
+    uint16_t *dst = row_stage + ((int64_t)b * rows + r) * stage_cap;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (keep[q]) { if (p2 < stage_cap) dst[p2] = pm[t * 4 + q]; p2++; }
     if (t == 0) row_count[b * rows + r] = total;
 }
 
@@ -231,9 +346,11 @@ hipError_t launch_peaks(hipStream_t st, PeakSrc src, int B, int rows, int cols, 
                         int stage_cap, int32_t *row_count, int32_t *out, int32_t cap, int32_t *n_out)
 {
     const int half = (cols + 1) / 2;
-    size_t lds = sizeof(float) * (size_t)(cols + 2 * half) + sizeof(uint16_t) * (size_t)half + 16;
+    size_t lds = sizeof(float) * (size_t)(cols + cols / 8 + 2 + 2 * half) + sizeof(uint16_t) * (size_t)half + 16;
     dim3 grid(rows, B), block(PK_T);
-    if (src.is_u8)
+    if (src.is_u8 && cols <= PKF_MAXC && cols >= 3)
+        hipLaunchKernelGGL(peaks_rows_u8_kernel, grid, block, 0, st, src, rows, cols, row_stage, stage_cap, row_count);
+    else if (src.is_u8)
         hipLaunchKernelGGL(peaks_rows_kernel<true>, grid, block, lds, st, src, rows, cols, row_stage, stage_cap, row_count);
     else
         hipLaunchKernelGGL(peaks_rows_kernel<false>, grid, block, lds, st, src, rows, cols, row_stage, stage_cap, row_count);

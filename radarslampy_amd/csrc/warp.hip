@@ -175,7 +175,7 @@ hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
 #define WG_LB 8
 #define WG_TW 64          // tile width  (one wavefront = 64 consecutive pixels of a row)
 #define WG_TH 16          // tile height
-#define WG_BOX_BYTES 12288
+#define WG_BOX_ELEMS 4096     // polar samples staged per tile, already decoded to float32 (16 KB)
 // 256-thread block = 64 x 16 pixel tile; wave w owns rows 4w..4w+3, lane = x offset.
 // The polar footprint of a tile is a small box (range span x azimuth span): it is staged in
 // LDS with coalesced row loads (one wavefront per polar row, 64 consecutive bytes per load) and
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
                                                           int64_t u8_lane_stride)
 {
     __shared__ __align__(16) uint8_t tile[WG_TH][WG_TW];
-    __shared__ __align__(16) uint8_t box[WG_BOX_BYTES];
+    __shared__ __align__(16) float box[WG_BOX_ELEMS];
     __shared__ int red[4][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = blockIdx.x * WG_TW + lane;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     }
     const bool any = mxx >= 0;
     const int bw = mxx - mnx + 2, bh = mxy - mny + 2;
-    const bool use_box = any && (bw * bh <= WG_BOX_BYTES);
+    const bool use_box = any && (bw * bh <= WG_BOX_ELEMS);
     int off0[4], off1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
                 int r = mny + k - 1;
                 if (r < 0) r += rows; else if (r >= rows) r -= rows;
                 const uint8_t *src = p + (int64_t)r * row_stride + mnx;
-                for (int c = lane; c < bw; c += 64) box[k * bw + c] = (mnx + c < cols) ? src[c] : (uint8_t)0;
+                for (int c = lane; c < bw; c += 64) box[k * bw + c] = (mnx + c < cols) ? code_to_f32(src[c]) : 0.f;
             }
             __syncthreads();
         }
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             if (in0[j]) {
                 float s00, s01, s10, s11;
                 if (use_box) {
-                    s00 = code_to_f32(box[off0[j]]); s01 = code_to_f32(box[off0[j] + 1]);
-                    s10 = code_to_f32(box[off1[j]]); s11 = code_to_f32(box[off1[j] + 1]);
+                    s00 = box[off0[j]]; s01 = box[off0[j] + 1];
+                    s10 = box[off1[j]]; s11 = box[off1[j] + 1];
                 } else {
                     const bool i1 = ixv[j] + 1 < cols;
                     s00 = code_to_f32(p[off0[j]]); s01 = i1 ? code_to_f32(p[off0[j] + 1]) : 0.f;
