@@ -168,6 +168,9 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg);
 int32_t roam_engine_destroy(roam_ctx *ctx);
 /* copy one raw record (rows x stride u8) into pool slot idx */
 int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *rec);
+/* device-to-device copy of a resident record (lets a benchmark give every lane its own copy of a
+ * scan so that input reads are real HBM traffic rather than L2 / Infinity-Cache hits) */
+int32_t roam_engine_copy_scan(roam_ctx *ctx, int32_t dst_idx, int32_t src_idx);
 /* initialise a lane from a pool scan: pyramid of that scan becomes "previous", features =
  * pts (K,2) f32 pixel [x,y], pose = pose3.  (First-frame feature detection is a4/a5.) */
 int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const float *pts,

@@ -58,6 +58,7 @@ _SIGS = {
     "roam_engine_create": (C.c_int32, [_vp, _P(EngineCfg)]),
     "roam_engine_destroy": (C.c_int32, [_vp]),
     "roam_engine_upload_scan": (C.c_int32, [_vp, C.c_int32, _vp]),
+    "roam_engine_copy_scan": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "roam_engine_init_lane": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
     "roam_engine_step": (C.c_int32, [_vp, _vp]),
     "roam_engine_results": (C.c_int32, [_vp, _P(LaneResult), C.c_int32]),

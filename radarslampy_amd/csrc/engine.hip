@@ -408,6 +408,16 @@ int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *
     return ROAM_OK;
 }
 
+int32_t roam_engine_copy_scan(roam_ctx *ctx, int32_t dst_idx, int32_t src_idx)
+{
+    ENGINE();
+    ARG_CHECK(ctx, dst_idx >= 0 && dst_idx < e->cfg.pool_scans && src_idx >= 0 && src_idx < e->cfg.pool_scans);
+    if (dst_idx != src_idx)
+        HIP_TRY(ctx, hipMemcpyAsync(e->pool + (size_t)dst_idx * e->rec_bytes, e->pool + (size_t)src_idx * e->rec_bytes,
+                                    e->rec_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ROAM_OK;
+}
+
 static WarpSrc pool_warp_src(Engine *e, const int32_t *lane_index)
 {
     WarpSrc s = {e->pool, (int64_t)e->rec_bytes, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, lane_index};

@@ -35,6 +35,9 @@ class Engine:
         assert rec.shape == (self.rows, self.stride), rec.shape
         self.ctx.check(self.lib.roam_engine_upload_scan(self.ctx.h, int(pool_idx), _ffi._ptr(rec)))
 
+    def copy_scan(self, dst_idx: int, src_idx: int):
+        self.ctx.check(self.lib.roam_engine_copy_scan(self.ctx.h, int(dst_idx), int(src_idx)))
+
     def init_lane(self, lane: int, pool_idx: int, pts: np.ndarray, pose):
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
         pose = np.ascontiguousarray(pose, np.float64)
