@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
     ap.add_argument("--kernel-reps", type=int, default=10)
+    ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -57,41 +58,57 @@ def main():
 
     ctx = _ffi.Context(local_rank)
     info = ctx.device_info()
+    E = max(1, args.engines)
     B, T, D = args.lanes, args.frames, max(1, min(args.distinct, args.lanes))
+    assert B % E == 0
+    BE = B // E
     seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, n_static=460, n_movers=24, distortion=not args.no_md) for d in range(D)]
     # every lane owns private copies of its T records (device-to-device replicas of the D distinct
     # sequences): identical content, distinct HBM addresses -> input reads are real HBM traffic
-    eng = Engine(B, B * T, ctx=ctx, motion_distortion=not args.no_md)
-    for d, (recs, poses, feat) in enumerate(seqs):
-        for t in range(T):
-            eng.upload_scan(d * T + t, recs[t])          # lanes 0..D-1 hold the originals
-    for b in range(D, B):
-        for t in range(T):
-            eng.copy_scan(b * T + t, (b % D) * T + t)
-    for b in range(B):
-        d = b % D
-        eng.init_lane(b, b * T, seqs[d][2], seqs[d][1][0])
+    ctxs = [ctx] + [_ffi.Context(local_rank) for _ in range(E - 1)]
+    engs = []
+    for e in range(E):
+        en = Engine(BE, BE * T, ctx=ctxs[e], motion_distortion=not args.no_md)
+        Dn = min(D, BE)
+        for d in range(Dn):
+            for t in range(T):
+                en.upload_scan(d * T + t, seqs[d][0][t])      # lanes 0..D-1 hold the originals
+        for b in range(Dn, BE):
+            for t in range(T):
+                en.copy_scan(b * T + t, (b % Dn) * T + t)
+        for b in range(BE):
+            d = b % Dn
+            en.init_lane(b, b * T, seqs[d][2], seqs[d][1][0])
+        engs.append(en)
+    eng = engs[0]
 
     # ping-pong frame schedule 1,2,..,T-1,T-2,..,0,1,..
     cyc = list(range(1, T)) + list(range(T - 2, -1, -1))
 
     def idx(step):
         t = cyc[step % len(cyc)]
-        return np.array([b * T + t for b in range(B)], np.int32)
+        return np.array([b * T + t for b in range(BE)], np.int32)
+
+    def step_all(i):
+        ix = idx(i)
+        for en in engs:
+            en.step(ix)
 
     def barrier():
-        eng.synchronize()
+        for en in engs:
+            en.synchronize()
         if dist is not None:
             dist.barrier()
-            eng.synchronize()
+            for en in engs:
+                en.synchronize()
 
     s = 0
     for _ in range(args.warmup):
-        eng.step(idx(s)); s += 1
+        step_all(s); s += 1
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.step(idx(s)); s += 1
+        step_all(s); s += 1
     barrier()
     dt = time.perf_counter() - t0
     res = eng.results()
@@ -146,7 +163,7 @@ def main():
             "data": f"synthetic Oxford-format 400x3779 u8 records; {D} distinct seeded sequences x {T} frames per rank, replicated into {B} lane-private HBM copies, ping-pong replay",
             "config": {"workload": "steady-state scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
                                    + ("motion-distortion LM" if not args.no_md else "dead reckoning") + ")",
-                       "lanes_per_gpu": B, "frames": T, "device": info["name"], "arch": info["arch"],
+                       "lanes_per_gpu": B, "engines_per_gpu": E, "frames": T, "device": info["name"], "arch": info["arch"],
                        "initial_features": int(np.mean([len(q[2]) for q in seqs])),
                        "mean_tracked": round(float(np.mean([r["n_tracked"] for r in res])), 1),
                        "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
@@ -154,8 +171,10 @@ def main():
                        "whole_path_Bmin_GBs_per_gpu": round(path_gbs, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-    eng.close()
-    ctx.close()
+    for en in engs:
+        en.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
