@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
 {
     __shared__ short It[18][18];
     __shared__ short Dx[16][16], Dy[16][16];
-    __shared__ short Jt[32][33];          // cached 32x32 neighbourhood of the next image (reloaded only when the window leaves it)
+    __shared__ __align__(16) uint8_t Jt8[32][36];   // cached 32x32 u8 neighbourhood of the next image (reloaded only when the window leaves it)
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     if (count && k >= count[b]) return;
     const int64_t pidx = ((int64_t)b * kstride + k) * 2;
@@ -276,13 +276,22 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
     float out_x = 0.f, out_y = 0.f, er = 0.f;
     int st = 1;
 
-    // patch sample coordinates owned by this lane
+    // window pixels owned by this lane: row ry, columns 4g .. 4g+3 (15 x 15 window -> lanes 0..59, the
+    // last group holds 3 pixels).  Four CONSECUTIVE pixels per lane let one pair of dword LDS reads per
+    // image row feed all their bilinear taps (the first version read 16 shorts per lane and iteration
+    // and was LDS-bound: PMC SQ_LDS_IDX_ACTIVE 80 % of the kernel).
+    const int ry = lane >> 2, g4 = (lane & 3) * 4;
     int py_[4], px_[4];
+    bool pv_[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int p = lane + 64 * q;
-        py_[q] = p / KW; px_[q] = p - py_[q] * KW;
-    }
+    for (int q = 0; q < 4; q++) { py_[q] = ry; px_[q] = g4 + q; pv_[q] = (ry < KW) && (g4 + q < KW); }
+    // five consecutive bytes starting at column x0 of tile row y (two aligned dword reads)
+    auto row5 = [&](int y, int x0, int (&out)[5]) {
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(&Jt8[y][x0 & ~3]);
+        const unsigned long long v = (((unsigned long long)rp[1] << 32) | rp[0]) >> (8 * (x0 & 3));
+#pragma unroll
+        for (int i = 0; i < 5; i++) out[i] = (int)((v >> (8 * i)) & 255ull);
+    };
 
     for (int level = ROAM_PYR_LEVELS - 1; level >= 0; level--) {
         const int w = d.w[level], h = d.h[level];
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             Iv[q] = 0; Ix[q] = 0; Iy[q] = 0;
-            if (lane + 64 * q < KW * KW) {
+            if (pv_[q]) {
                 int y = py_[q], x = px_[q];
                 Iv[q] = DESCALE(It[y + 1][x + 1] * iw00 + It[y + 1][x + 2] * iw01 + It[y + 2][x + 1] * iw10 + It[y + 2][x + 2] * iw11, W_BITS - 5);
                 Ix[q] = DESCALE(Dx[y][x] * iw00 + Dx[y][x + 1] * iw01 + Dx[y + 1][x] * iw10 + Dx[y + 1][x + 1] * iw11, W_BITS);
@@ -370,21 +379,25 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                 __syncthreads();
                 for (int i = lane; i < 32 * 32; i += 64) {
                     int y = i >> 5, x = i & 31;
-                    Jt[y][x] = (short)J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
+                    Jt8[y][x] = J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
                 }
                 __syncthreads();
             }
             const int jox = inx - tx0, joy = iny - ty0;
             long long sb1 = 0, sb2 = 0;
+            if (ry < KW) {
+                int ra[5], rb[5];
+                row5(joy + ry, jox + g4, ra);
+                row5(joy + ry + 1, jox + g4, rb);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (lane + 64 * q < KW * KW) {
-                    int y = joy + py_[q], x = jox + px_[q];
-                    int jv = DESCALE(Jt[y][x] * iw00 + Jt[y][x + 1] * iw01 + Jt[y + 1][x] * iw10 + Jt[y + 1][x + 1] * iw11, W_BITS - 5);
-                    int diff = jv - Iv[q];
-                    sb1 += (long long)diff * Ix[q];
-                    sb2 += (long long)diff * Iy[q];
-                }
+                for (int q = 0; q < 4; q++)
+                    if (pv_[q]) {
+                        int jv = DESCALE(ra[q] * iw00 + ra[q + 1] * iw01 + rb[q] * iw10 + rb[q + 1] * iw11, W_BITS - 5);
+                        int diff = jv - Iv[q];
+                        sb1 += (long long)diff * Ix[q];
+                        sb2 += (long long)diff * Iy[q];
+                    }
+            }
             sb1 = wave_sum_ll(sb1); sb2 = wave_sum_ll(sb2);
             const float b1 = __fmul_rn(__ll2float_rn(sb1), FLT_SCALE);
             const float b2 = __fmul_rn(__ll2float_rn(sb2), FLT_SCALE);
@@ -410,20 +423,24 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                 __syncthreads();
                 for (int i = lane; i < 32 * 32; i += 64) {
                     int y = i >> 5, x = i & 31;
-                    Jt[y][x] = (short)J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
+                    Jt8[y][x] = J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
                 }
                 __syncthreads();
             }
             const int eox = iex - tx0, eoy = iey - ty0;
             long long se = 0;
+            if (ry < KW) {
+                int ra[5], rb[5];
+                row5(eoy + ry, eox + g4, ra);
+                row5(eoy + ry + 1, eox + g4, rb);
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (lane + 64 * q < KW * KW) {
-                    int y = eoy + py_[q], x = eox + px_[q];
-                    int jv = DESCALE(Jt[y][x] * iw00 + Jt[y][x + 1] * iw01 + Jt[y + 1][x] * iw10 + Jt[y + 1][x + 1] * iw11, W_BITS - 5);
-                    int diff = jv - Iv[q];
-                    se += diff < 0 ? -diff : diff;
-                }
+                for (int q = 0; q < 4; q++)
+                    if (pv_[q]) {
+                        int jv = DESCALE(ra[q] * iw00 + ra[q + 1] * iw01 + rb[q] * iw10 + rb[q + 1] * iw11, W_BITS - 5);
+                        int diff = jv - Iv[q];
+                        se += diff < 0 ? -diff : diff;
+                    }
+            }
             se = wave_sum_ll(se);
             er = __fmul_rn(__ll2float_rn(se), 1.f / (float)(32 * KW * KW));
         }
