@@ -274,7 +274,7 @@ __device__ void lmpar6(int m, double *a, const int *ipvt, const double *diag, co
 __global__ __launch_bounds__(LM_TMAX) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
                                                       double *__restrict__ out6, int32_t *__restrict__ nfev_out,
                                                       int32_t *__restrict__ info_out, double *__restrict__ x0_out,
-                                                      double *__restrict__ r0_out)
+                                                      double *__restrict__ r0_out, int lds_bytes)
 {
     extern __shared__ __align__(16) unsigned char lm_smem[];
     __shared__ LmShared S;
@@ -282,11 +282,15 @@ __global__ __launch_bounds__(LM_TMAX) void mds_lm_kernel(MdsProblemDesc P, doubl
     const int N = P.count ? min(P.count[b], P.nmax) : P.N;
     const int m = 2 * N + 3, n = 6;
     const int mmax = 2 * P.nmax + 3;
-    const size_t need = ((size_t)mmax * 9 + P.nmax) * sizeof(double);
-    double *work = (need <= LM_LDS_BYTES) ? reinterpret_cast<double *>(lm_smem)
-                                          : work_g + (size_t)b * ((size_t)mmax * 9 + P.nmax);
-    double *fvec = work, *a = work + mmax, *wa4 = a + (size_t)6 * mmax, *wf = wa4 + mmax, *dT = wf + mmax;
-    // NOTE: columns of `a` are spaced m apart (A_ macro), all inside the 6*mmax slab.
+    // working set sized by THIS problem's point count: it lives in LDS whenever it fits the dynamic
+    // LDS the launch provided (lds_bytes, sized from the host-side bound nmax and capped at 64 KB),
+    // otherwise in the L2-resident global slab
+    const size_t need = ((size_t)m * 9 + N) * sizeof(double);
+    const bool in_lds = need <= (size_t)lds_bytes;
+    double *work = in_lds ? reinterpret_cast<double *>(lm_smem) : work_g + (size_t)b * ((size_t)mmax * 9 + P.nmax);
+    const int ms = in_lds ? m : mmax;                  // slab stride
+    double *fvec = work, *a = work + ms, *wa4 = a + (size_t)6 * ms, *wf = wa4 + ms, *dT = wf + ms;
+    // NOTE: columns of `a` are spaced m apart (A_ macro), all inside the 6*ms slab.
     const double *p_w = P.p_w + (size_t)b * P.nstride * 2;
     const double *p_jt = P.p_jt + (size_t)b * P.nstride * 2;
     const double *T0 = P.T_wj0 + (size_t)b * 9, *Ti = P.T_init + (size_t)b * 9;
@@ -539,11 +543,14 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     if (p.B <= 0) return hipSuccess;
     const size_t mmax = 2 * (size_t)p.nmax + 3;
     size_t need = (mmax * 9 + p.nmax) * sizeof(double);
-    size_t lds = need <= LM_LDS_BYTES ? need : 0;
+    // LDS per workgroup caps how many solves a CU runs concurrently, and the solve is latency-bound:
+    // 32 KB (N <= 214) keeps 4-5 workgroups per CU; measured 64 KB -> 2 per CU was 30 % slower
+    const size_t cap = 32768;
+    size_t lds = need <= cap ? need : cap;
     // the solve is a long chain of short reductions: with few points a single wavefront per problem
     // (workgroup barriers degenerate to no-ops, reductions stay in registers) has the lowest latency
     const int threads = p.nmax <= 192 ? 64 : (p.nmax <= 448 ? 128 : LM_TMAX);
-    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out);
+    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds);
     return hipGetLastError();
 }
 
