@@ -32,3 +32,28 @@ def convertPolarImageToCartesian(imgPolar: np.ndarray, logPolarMode: bool = Fals
         raise NotImplementedError("only the reference's live configuration (linear, downsampleFactor=2) is built")
     cart, _ = _ffi.default_context().polar_to_cart_f32(imgPolar, want_f32=True, want_u8=False)
     return cart
+
+
+def getRadarImgPaths(dataPath: str, timestampPath: str):
+    """list of '<dataPath>/<stamp>.png' for every line of radar.timestamps (parseData.py:208-226; like the
+    reference, the string valid flag is truthy for every line)"""
+    import os
+    imgPathArr = []
+    with open(timestampPath, "r") as f:
+        for line in f.readlines():
+            stamp, valid = line.strip().split(" ")
+            if valid:
+                imgPathArr.append(os.path.join(dataPath, stamp + ".png"))
+    return imgPathArr
+
+
+def readRadarRecord(imgPath: str) -> np.ndarray:
+    """(400, 3779) u8 Oxford record from a PNG (the reference uses cv2.imread(..., IMREAD_GRAYSCALE),
+    parseData.py:178; Pillow decodes the same 8-bit greyscale PNG).  PNG inflate is host work (§8f-f2)."""
+    from PIL import Image
+    return np.array(Image.open(imgPath).convert("L"), dtype=np.uint8)
+
+
+def getPolarImageFromImgPaths(imgPathArr, index: int) -> np.ndarray:
+    polar, _, _, _, _, _ = extractDataFromRadarImage(readRadarRecord(imgPathArr[index]))
+    return polar

@@ -124,3 +124,22 @@ def test_u8_decode_identity():
     ref = k.astype(np.float32) / np.float32(255.)
     got = (k.astype(np.float64) * (1.0 / 255.0)).astype(np.float32)
     assert np.array_equal(got, ref)
+
+
+def test_trajectory_and_gt_loader(tmp_path):
+    from radarslampy_amd.trajectoryPlotting import Trajectory, getGroundTruthTrajectory, computePosesRMSE
+    p = tmp_path / "radar_odometry.csv"
+    rows = ["source_timestamp,destination_timestamp,x,y,z,roll,pitch,yaw,source_radar_timestamp,destination_radar_timestamp"]
+    for i in range(6):
+        rows.append(f"{i},{i},1.0,0.0,0,0,0,{0.1 if i % 2 else 0.0},{100 + i},{100 + i}")
+    p.write_text("\n".join(rows) + "\n")
+    gt = getGroundTruthTrajectory(str(p))
+    assert gt.poses.shape == (6, 3) and abs(gt.poses[0, 0] - 1.0) < 1e-12 and gt.gt_deltas[101] == [1.0, 0.0, 0.1]
+    tr = Trajectory([0], [np.zeros(3)])
+    tr.appendRelativeDeltas(1, [1.0, 0.0, np.pi / 2])
+    tr.appendRelativeDeltas(2, [1.0, 0.0, 0.0])
+    assert np.allclose(tr.poses[-1], [1.0, 1.0, np.pi / 2])
+    tr.appendAbsoluteTransform(3, np.array([5.0, 5.0, 0.0]))
+    assert tr.poses.shape == (4, 3)
+    assert abs(computePosesRMSE(np.zeros((3, 3)), np.array([[3, 4, 0.0]] * 3)) - 5.0) < 1e-12
+    assert np.allclose(gt.getPoseAtTimes(102), gt.poses[2], atol=1e-9)

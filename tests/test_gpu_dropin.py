@@ -81,3 +81,33 @@ def test_misc_dropins(golden):
     k = golden("kabsch")
     R, h = calculateTransformSVD(k["real95_f32_src"], k["real95_f32_tgt"])
     assert np.abs(h - k["real95_f32_h"]).max() * 0.0864 <= 1e-4
+
+
+def test_raw_roam_system_driver_on_png_sequence(tmp_path):
+    """The non-plotting RawROAMSystem driver over a synthetic Oxford-format sequence stored as PNGs:
+    frame-by-frame poses equal the oracle's loop body (detect -> track -> reject -> Kabsch -> LM ->
+    keyframe / retrack) within 1e-4 m / 1e-5 rad."""
+    from PIL import Image
+    from radarslampy_amd import synth
+    from radarslampy_amd.RawROAMSystem import RawROAMSystem
+    recs, poses, _ = synth.make_sequence(9, 4)
+    root = tmp_path / "data"
+    rad = root / "synth" / "radar"
+    rad.mkdir(parents=True)
+    stamps = [1547131046353776 + 250000 * i for i in range(len(recs))]
+    with open(root / "synth" / "radar.timestamps", "w") as f:
+        for s_, r in zip(stamps, recs):
+            Image.fromarray(r).save(rad / f"{s_}.png")
+            f.write(f"{s_} 1\n")
+    sysm = RawROAMSystem("synth", {"rejectOutliers": True}, hasGroundTruth=False, dataRoot=str(root))
+    sysm.run(0, -1, initPose=poses[0])
+    feat0 = oracle.getFeatures(oracle.convertPolarImageToCartesian(recs[0][:, 11:11 + 2025].astype(np.float32) / 255.))[0]
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), feat0)
+    pipe = oracle.OdometryPipeline(recs[0], feat0, poses[0], detect=lambda c: oracle.getFeatures(c)[0])
+    assert len(sysm.frameLog) == 3
+    for t, log in zip(range(1, 4), sysm.frameLog):
+        want = pipe.step(recs[t])
+        assert log["n_tracked"] == want["n_tracked"] and log["n_inliers"] == want["n_inliers"], t
+        assert np.abs(log["pose"][:2] - want["pose"][:2]).max() <= 1e-4 and abs(log["pose"][2] - want["pose"][2]) <= 1e-5, t
+        assert log["new_keyframe"] == bool(want["new_keyframe"])
+    assert sysm.estTraj.poses.shape == (4, 3)
