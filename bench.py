@@ -167,6 +167,7 @@ def main():
                        "initial_features": int(np.mean([len(q[2]) for q in seqs])),
                        "mean_tracked": round(float(np.mean([r["n_tracked"] for r in res])), 1),
                        "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
+                       "mean_lm_nfev": round(float(np.mean([r["lm_nfev"] for r in res])), 1),
                        "stage_ms_last_step": {k: round(v, 4) for k, v in stages.items()},
                        "whole_path_Bmin_GBs_per_gpu": round(path_gbs, 3)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -281,6 +281,10 @@ __global__ __launch_bounds__(LM_TMAX) void mds_lm_kernel(MdsProblemDesc P, doubl
     const int b = blockIdx.x, t = threadIdx.x;
     const int N = P.count ? min(P.count[b], P.nmax) : P.N;
     const int m = 2 * N + 3, n = 6;
+    if (N < 2) {                                      // lmdif needs m >= n; the caller keeps the previous pose
+        if (t == 0) { nfev_out[b] = 0; info_out[b] = -1; for (int j = 0; j < 6; j++) out6[(size_t)b * 6 + j] = 0.0; }
+        return;
+    }
     const int mmax = 2 * P.nmax + 3;
     // working set sized by THIS problem's point count: it lives in LDS whenever it fits the dynamic
     // LDS the launch provided (lds_bytes, sized from the host-side bound nmax and capped at 64 KB),

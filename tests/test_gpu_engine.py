@@ -100,3 +100,31 @@ def test_engine_retrack_matches_oracle(sequences):
     assert saw_retrack and len(pipe.blobCoord) > 150
     eng.close()
     ctx.close()
+
+
+def test_engine_degenerate_lanes(sequences):
+    """Lanes with 0, 1 and 3 features next to a healthy lane: nothing hangs, the starved lanes keep
+    their pose and raise the retrack flag, the healthy lane is unaffected."""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = sequences[0]
+    ctx = _ffi.Context(0)
+    eng = Engine(4, 2, ctx=ctx)
+    eng.upload_scan(0, recs[0])
+    eng.upload_scan(1, recs[1])
+    sets = [feat[:0], feat[:1], feat[:3], feat]
+    for b, f in enumerate(sets):
+        eng.init_lane(b, 0, f, poses[0])
+    eng.step([1, 1, 1, 1])
+    res = eng.results()
+    ref = oracle.OdometryPipeline(recs[0], feat, poses[0])
+    want = ref.step(recs[1])
+    assert res[3]["n_inliers"] == want["n_inliers"]
+    assert np.abs(res[3]["pose"][:2] - want["pose"][:2]).max() <= POS_TOL
+    for b in (0, 1):
+        assert res[b]["n_inliers"] <= 1 and res[b]["retrack"]
+        assert np.allclose(res[b]["pose"], poses[0])
+    assert res[2]["retrack"] and res[2]["n_inliers"] <= 3 and np.all(np.isfinite(res[2]["pose"]))
+    assert res[0]["n_peaks"] == res[3]["n_peaks"] == want["n_peaks"]
+    eng.close()
+    ctx.close()
