@@ -21,33 +21,34 @@
 //   slab (nw words per level, L2-resident).  No MFMA: the work is integer bit algebra.
 #include "roam_internal.h"
 
+#define CG_ROWS 8       // adjacency rows per workgroup
 __global__ __launch_bounds__(256) void consistency_graph_kernel(const float *__restrict__ prev,
                                                                 const float *__restrict__ next,
                                                                 const int32_t *__restrict__ count, int K,
                                                                 int kstride, double thr,
                                                                 uint64_t *__restrict__ adj, int nw, int nws)
 {
-    const int i = blockIdx.y, b = blockIdx.z;
+    const int i0 = blockIdx.x * CG_ROWS, b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + wave;
     const int Kb = count ? min(count[b], K) : K;
-    if (w >= nw) return;
-    uint64_t word = 0;
-    if (i < Kb) {
+    if (i0 >= Kb) return;                              // the host bound K only shrinks at (re)seeds: most rows are past the live count
+    const int nwb = (Kb + 63) >> 6;                    // words that can hold a set bit for this lane
+    const float *P = prev + (int64_t)b * kstride * 2, *N = next + (int64_t)b * kstride * 2;
+    for (int job = wave; job < CG_ROWS * nwb; job += 4) {
+        const int i = i0 + job / nwb, w = job % nwb;
+        if (i >= Kb) continue;
         const int j = w * 64 + lane;
         bool e = false;
         if (j < Kb && j != i) {
-            const float *pi = prev + ((int64_t)b * kstride + i) * 2, *pj = prev + ((int64_t)b * kstride + j) * 2;
-            const float *ni = next + ((int64_t)b * kstride + i) * 2, *nj = next + ((int64_t)b * kstride + j) * 2;
-            double ax = __dsub_rn((double)pi[0], (double)pj[0]), ay = __dsub_rn((double)pi[1], (double)pj[1]);
-            double bx = __dsub_rn((double)ni[0], (double)nj[0]), by = __dsub_rn((double)ni[1], (double)nj[1]);
+            double ax = __dsub_rn((double)P[2 * i], (double)P[2 * j]), ay = __dsub_rn((double)P[2 * i + 1], (double)P[2 * j + 1]);
+            double bx = __dsub_rn((double)N[2 * i], (double)N[2 * j]), by = __dsub_rn((double)N[2 * i + 1], (double)N[2 * j + 1]);
             double d0 = __dsqrt_rn(__dadd_rn(__dmul_rn(ax, ax), __dmul_rn(ay, ay)));
             double d1 = __dsqrt_rn(__dadd_rn(__dmul_rn(bx, bx), __dmul_rn(by, by)));
             e = fabs(__dsub_rn(d0, d1)) <= thr;
         }
-        word = __ballot(e);
+        const uint64_t word = __ballot(e);
+        if (lane == 0) adj[((int64_t)b * kstride + i) * nws + w] = word;
     }
-    if (lane == 0) adj[((int64_t)b * kstride + i) * nws + w] = word;
 }
 
 hipError_t launch_consistency_graph(hipStream_t st, const float *prev, const float *next,
@@ -55,8 +56,8 @@ hipError_t launch_consistency_graph(hipStream_t st, const float *prev, const flo
                                     uint64_t *adj, int nws)
 {
     if (K <= 0 || B <= 0) return hipSuccess;
-    const int nw = (K + 63) / 64;            // words that can hold a set bit
-    dim3 grid((nw + 3) / 4, K, B);
+    const int nw = (K + 63) / 64;
+    dim3 grid((K + CG_ROWS - 1) / CG_ROWS, B);
     hipLaunchKernelGGL(consistency_graph_kernel, grid, dim3(256), 0, st, prev, next, count, K, kstride, thr, adj, nw, nws);
     return hipGetLastError();
 }
