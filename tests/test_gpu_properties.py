@@ -1,0 +1,112 @@
+"""GPU (-m gpu): size-independent properties at BASELINE's full sizes and at the build's limits."""
+import numpy as np
+import pytest
+
+import oracle
+from gen_inputs import unique_clique_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from radarslampy_amd import _ffi
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+def test_peaks_properties_full_width_record(ctx):
+    """400 x 3768 bins (unclipped Oxford row): every reported bin is a strict local maximum / plateau
+    midpoint, rows and bins ascend, and every kept height clears its row's mean + std."""
+    from radarslampy_amd import synth
+    rec = synth.make_sequence(11, 1)[0][0]
+    pts = ctx.peaks_record_u8(rec, payload_off=11, clip=3768)
+    assert len(pts) > 1000
+    key = pts[:, 0].astype(np.int64) * 4096 + pts[:, 1]
+    assert np.all(np.diff(key) > 0)                                      # azimuth-major, range ascending
+    row = rec[:, 11:].astype(np.int32)
+    a, r = pts[:, 0], pts[:, 1]
+    assert np.all((r >= 1) & (r <= 3766))
+    v = row[a, r]
+    assert np.all(row[a, r - 1] <= v) and np.all(row[a, r + 1] <= v)       # plateau midpoints allow equality
+    assert np.array_equal(pts, oracle.peaks_from_record_u8(rec, 11, 3768))
+
+
+def test_clique_properties_at_capacity(ctx):
+    """K = 1024 (the build's K_max, adjacency read through L2) and K = 600: the mask is a clique, it
+    is maximal (no outside vertex is adjacent to all members), and equals the planted inlier set."""
+    for K, seed in [(600, 31), (1024, 32)]:
+        p, n, inl = unique_clique_pairs(K, seed, 0.3)
+        mask, n_in, flags, adj = ctx.reject_outliers(p, n, oracle.DIST_THRESHOLD_PX, want_adj=True)
+        assert flags & 1
+        A = oracle.adjacency_dense(adj, K)
+        idx = np.flatnonzero(mask)
+        assert A[np.ix_(idx, idx)][~np.eye(len(idx), dtype=bool)].all()
+        outside = np.flatnonzero(~mask)
+        assert not A[np.ix_(outside, idx)].all(axis=1).any()
+        assert n_in == inl.sum() and np.array_equal(mask, inl)
+
+
+def test_klt_many_points_and_determinism(ctx, golden):
+    g = golden("peaks")
+    a = oracle.convertPolarImageToCartesian(g["real0_u8"].astype(np.float32) / 255., want_u8=True)[1]
+    b = oracle.convertPolarImageToCartesian(g["real1_u8"].astype(np.float32) / 255., want_u8=True)[1]
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-30, 2054, size=(1024, 2)).astype(np.float32)          # includes points outside the image
+    n1, s1, e1 = ctx.klt_track(a, b, pts)
+    n2, s2, e2 = ctx.klt_track(a, b, pts)
+    assert np.array_equal(n1, n2) and np.array_equal(s1, s2) and np.array_equal(e1, e2)
+    wn, ws, we = oracle.calcOpticalFlowPyrLK(a, b, pts)
+    assert np.array_equal(n1, wn) and np.array_equal(s1, ws) and np.array_equal(e1, we)
+    # tracking an image onto itself leaves every trackable point where it is
+    n0, s0, e0 = ctx.klt_track(a, a, pts)
+    good = s0.flatten() == 1
+    assert np.abs(n0[good] - pts[good]).max() < 1e-3 and e0[good].max() == 0
+
+
+def test_lm_large_small_problems_and_determinism(ctx):
+    from gen_inputs import mds_problem
+    sigma5 = np.array([4, 4, 1, 1, (5 * np.pi / 180) ** 2])
+    for N, seed in [(12, 1), (333, 2), (1024, 3)]:
+        T0, p_w, p_jt, Ti, truth = mds_problem(N, seed, 0.08)
+        s1, nf1, info1, x0, r0 = ctx.mds_solve(T0, p_w, p_jt, Ti, sigma5, want_debug=True)
+        s2, nf2, info2, _, _ = ctx.mds_solve(T0, p_w, p_jt, Ti, sigma5)
+        assert np.array_equal(s1, s2) and nf1 == nf2
+        assert np.isfinite(s1).all() and 1 <= info1 <= 4
+        want = oracle.MotionDistortionSolver(np.diag([4, 4]), np.diag([1, 1, (5 * np.pi / 180) ** 2]))
+        want.update_problem(T0, p_w, p_jt, Ti)
+        ws = want.optimize_library()
+        assert np.abs(s1[3:5] - ws[3:5]).max() <= 1e-4 and abs(s1[5] - ws[5]) <= 1e-5, N
+
+
+def test_engine_lanes_are_independent_and_deterministic():
+    """Identical lanes give identical results; a lane's result does not depend on its neighbours."""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(21, 3)
+    recs2, poses2, feat2 = synth.make_sequence(22, 3)
+    ctx = _ffi.Context(0)
+    eng = Engine(3, 6, ctx=ctx)
+    for t in range(3):
+        eng.upload_scan(t, recs[t])
+        eng.upload_scan(3 + t, recs2[t])
+    eng.init_lane(0, 0, feat, poses[0])
+    eng.init_lane(1, 3, feat2, poses2[0])
+    eng.init_lane(2, 0, feat, poses[0])
+    out = []
+    for t in (1, 2):
+        eng.step([t, 3 + t, t])
+        out.append(eng.results())
+    for r in out:
+        assert np.array_equal(r[0]["pose"], r[2]["pose"]) and r[0]["n_inliers"] == r[2]["n_inliers"]
+    assert np.array_equal(eng.lane_features(0), eng.lane_features(2))
+    solo = Engine(1, 3, ctx=_ffi.Context(0))
+    for t in range(3):
+        solo.upload_scan(t, recs[t])
+    solo.init_lane(0, 0, feat, poses[0])
+    for i, t in enumerate((1, 2)):
+        solo.step([t])
+        assert np.array_equal(solo.results()[0]["pose"], out[i][0]["pose"])
+    eng.close()
+    ctx.close()
