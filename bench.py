@@ -119,6 +119,22 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # BASELINE config 5: the only exchange the path has - every rank broadcasts one keyframe payload
+    # {pose, velocity, features, polar peaks} of its lane 0 over RCCL (untimed w.r.t. `value`, reported)
+    kf_ms = None
+    if dist is not None:
+        try:
+            from radarslampy_amd.distributed import broadcast_keyframe
+            mine = dict(pose=res[0]["pose"], velocity=res[0]["velocity"], features=eng.lane_features(0), peaks=eng.lane_peaks(0))
+            broadcast_keyframe(mine if rank == 0 else None, 0, dist)            # warm-up (communicator setup)
+            k0 = time.perf_counter()
+            for src in range(world):
+                got = broadcast_keyframe(mine if rank == src else None, src, dist)
+                assert got["features"].shape[1] == 2 and got["peaks"].shape[1] == 2
+            kf_ms = (time.perf_counter() - k0) * 1e3 / world
+        except Exception as e:                                                    # never lose the bench line over the extra
+            sys.stderr.write(f"[bench] keyframe broadcast skipped: {e}\n")
+
     out = None
     if rank == 0:
         pairs = B * args.steps * world
@@ -169,7 +185,8 @@ def main():
                        "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
                        "mean_lm_nfev": round(float(np.mean([r["lm_nfev"] for r in res])), 1),
                        "stage_ms_last_step": {k: round(v, 4) for k, v in stages.items()},
-                       "whole_path_Bmin_GBs_per_gpu": round(path_gbs, 3)},
+                       "whole_path_Bmin_GBs_per_gpu": round(path_gbs, 3),
+                       "keyframe_broadcast_ms": None if kf_ms is None else round(kf_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     for en in engs:
