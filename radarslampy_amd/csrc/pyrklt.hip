@@ -262,8 +262,8 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                                                  int kstride, float *__restrict__ next_out,
                                                  uint8_t *__restrict__ status_out, float *__restrict__ err_out)
 {
-    __shared__ short It[18][18];
-    __shared__ short Dx[16][16], Dy[16][16];
+    __shared__ __align__(16) uint8_t It8[18][20];               // 18x18 neighbourhood of the previous image (u8, dword rows)
+    __shared__ __align__(16) short Dx[16][20], Dy[16][20];      // Scharr derivatives, rows padded to 40 B
     __shared__ __align__(16) uint8_t Jt8[32][36];   // cached 32x32 u8 neighbourhood of the next image (reloaded only when the window leaves it)
     const int k = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     if (count && k >= count[b]) return;
@@ -315,39 +315,74 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
         __syncthreads();
         for (int i = lane; i < 18 * 18; i += 64) {
             int ty = i / 18, tx = i - ty * 18;
-            It[ty][tx] = (short)I[(int64_t)reflect101(ipy - 1 + ty, h) * w + reflect101(ipx - 1 + tx, w)];
+            It8[ty][tx] = I[(int64_t)reflect101(ipy - 1 + ty, h) * w + reflect101(ipx - 1 + tx, w)];
         }
         __syncthreads();
+        {   // Scharr derivatives of a 16x16 block: lane -> row y, columns xg..xg+3, three rows of 6 bytes each
+            const int y = lane >> 2, xg = (lane & 3) * 4;
+            int tr[3][6];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int i = lane + 64 * q;
-            int y = i >> 4, x = i & 15;
-            int X = ipx + x, Y = ipy + y;
-            int dx = 0, dy = 0;
-            if (X >= 0 && Y >= 0 && X < w && Y < h) {
-                int a00 = It[y][x], a01 = It[y][x + 1], a02 = It[y][x + 2];
-                int a10 = It[y + 1][x], a12 = It[y + 1][x + 2];
-                int a20 = It[y + 2][x], a21 = It[y + 2][x + 1], a22 = It[y + 2][x + 2];
-                dx = 3 * (a02 + a22 - a00 - a20) + 10 * (a12 - a10);
-                dy = 3 * (a20 + a22 - a00 - a02) + 10 * (a21 - a01);
+            for (int rr = 0; rr < 3; rr++) {
+                const uint32_t lo = *reinterpret_cast<const uint32_t *>(&It8[y + rr][xg]);
+                const uint32_t hi = *reinterpret_cast<const uint32_t *>(&It8[y + rr][xg + 4]);
+                tr[rr][0] = lo & 255; tr[rr][1] = (lo >> 8) & 255; tr[rr][2] = (lo >> 16) & 255; tr[rr][3] = lo >> 24;
+                tr[rr][4] = hi & 255; tr[rr][5] = (hi >> 8) & 255;
             }
-            Dx[y][x] = (short)dx; Dy[y][x] = (short)dy;
+            short dxs[4], dys[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int X = ipx + xg + i, Y = ipy + y;
+                int dx = 0, dy = 0;
+                if (X >= 0 && Y >= 0 && X < w && Y < h) {
+                    const int a00 = tr[0][i], a01 = tr[0][i + 1], a02 = tr[0][i + 2];
+                    const int a10 = tr[1][i], a12 = tr[1][i + 2];
+                    const int a20 = tr[2][i], a21 = tr[2][i + 1], a22 = tr[2][i + 2];
+                    dx = 3 * (a02 + a22 - a00 - a20) + 10 * (a12 - a10);
+                    dy = 3 * (a20 + a22 - a00 - a02) + 10 * (a21 - a01);
+                }
+                dxs[i] = (short)dx; dys[i] = (short)dy;
+            }
+            *reinterpret_cast<uint2 *>(&Dx[y][xg]) = make_uint2((uint32_t)(uint16_t)dxs[0] | ((uint32_t)(uint16_t)dxs[1] << 16),
+                                                                (uint32_t)(uint16_t)dxs[2] | ((uint32_t)(uint16_t)dxs[3] << 16));
+            *reinterpret_cast<uint2 *>(&Dy[y][xg]) = make_uint2((uint32_t)(uint16_t)dys[0] | ((uint32_t)(uint16_t)dys[1] << 16),
+                                                                (uint32_t)(uint16_t)dys[2] | ((uint32_t)(uint16_t)dys[3] << 16));
         }
         __syncthreads();
         int Iv[4], Ix[4], Iy[4];
         long long sA11 = 0, sA12 = 0, sA22 = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            Iv[q] = 0; Ix[q] = 0; Iy[q] = 0;
-            if (pv_[q]) {
-                int y = py_[q], x = px_[q];
-                Iv[q] = DESCALE(It[y + 1][x + 1] * iw00 + It[y + 1][x + 2] * iw01 + It[y + 2][x + 1] * iw10 + It[y + 2][x + 2] * iw11, W_BITS - 5);
-                Ix[q] = DESCALE(Dx[y][x] * iw00 + Dx[y][x + 1] * iw01 + Dx[y + 1][x] * iw10 + Dx[y + 1][x + 1] * iw11, W_BITS);
-                Iy[q] = DESCALE(Dy[y][x] * iw00 + Dy[y][x + 1] * iw01 + Dy[y + 1][x] * iw10 + Dy[y + 1][x + 1] * iw11, W_BITS);
-                sA11 += (long long)Ix[q] * Ix[q];
-                sA12 += (long long)Ix[q] * Iy[q];
-                sA22 += (long long)Iy[q] * Iy[q];
+        for (int q = 0; q < 4; q++) { Iv[q] = 0; Ix[q] = 0; Iy[q] = 0; }
+        if (ry < KW) {
+            // image taps: rows ry+1, ry+2 of the tile, columns g4+1 .. g4+5
+            int ia[5], ib[5];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const uint32_t lo = *reinterpret_cast<const uint32_t *>(&It8[ry + 1 + rr][g4]);
+                const uint32_t hi = *reinterpret_cast<const uint32_t *>(&It8[ry + 1 + rr][g4 + 4]);
+                int *dst = rr ? ib : ia;
+                dst[0] = (lo >> 8) & 255; dst[1] = (lo >> 16) & 255; dst[2] = lo >> 24; dst[3] = hi & 255; dst[4] = (hi >> 8) & 255;
             }
+            // derivative taps: rows ry, ry+1, columns g4 .. g4+4 (4 shorts + 1)
+            int xa[5], xb[5], ya[5], yb[5];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const uint2 vx = *reinterpret_cast<const uint2 *>(&Dx[ry + rr][g4]);
+                const uint2 vy = *reinterpret_cast<const uint2 *>(&Dy[ry + rr][g4]);
+                const int x4 = Dx[ry + rr][g4 + 4], y4 = Dy[ry + rr][g4 + 4];
+                int *dx_ = rr ? xb : xa, *dy_ = rr ? yb : ya;
+                dx_[0] = (short)(vx.x & 0xffff); dx_[1] = (short)(vx.x >> 16); dx_[2] = (short)(vx.y & 0xffff); dx_[3] = (short)(vx.y >> 16); dx_[4] = x4;
+                dy_[0] = (short)(vy.x & 0xffff); dy_[1] = (short)(vy.x >> 16); dy_[2] = (short)(vy.y & 0xffff); dy_[3] = (short)(vy.y >> 16); dy_[4] = y4;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (pv_[q]) {
+                    Iv[q] = DESCALE(ia[q] * iw00 + ia[q + 1] * iw01 + ib[q] * iw10 + ib[q + 1] * iw11, W_BITS - 5);
+                    Ix[q] = DESCALE(xa[q] * iw00 + xa[q + 1] * iw01 + xb[q] * iw10 + xb[q + 1] * iw11, W_BITS);
+                    Iy[q] = DESCALE(ya[q] * iw00 + ya[q + 1] * iw01 + yb[q] * iw10 + yb[q + 1] * iw11, W_BITS);
+                    sA11 += (long long)Ix[q] * Ix[q];
+                    sA12 += (long long)Ix[q] * Iy[q];
+                    sA22 += (long long)Iy[q] * Iy[q];
+                }
         }
         sA11 = wave_sum_ll(sA11); sA12 = wave_sum_ll(sA12); sA22 = wave_sum_ll(sA22);
         const float A11 = __fmul_rn(__ll2float_rn(sA11), FLT_SCALE);
@@ -377,9 +412,12 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
             if (!(inx >= tx0 && inx - tx0 <= 15 && iny >= ty0 && iny - ty0 <= 15)) {
                 tx0 = inx - 8; ty0 = iny - 8;
                 __syncthreads();
-                for (int i = lane; i < 32 * 32; i += 64) {
-                    int y = i >> 5, x = i & 31;
-                    Jt8[y][x] = J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
+                for (int i = lane; i < 32 * 8; i += 64) {            // 4 bytes per lane, one dword LDS write
+                    const int y = i >> 3, c4 = (i & 7) * 4;
+                    const uint8_t *jr = J + (int64_t)reflect101(ty0 + y, h) * w;
+                    const uint32_t pk = (uint32_t)jr[reflect101(tx0 + c4, w)] | ((uint32_t)jr[reflect101(tx0 + c4 + 1, w)] << 8) |
+                                        ((uint32_t)jr[reflect101(tx0 + c4 + 2, w)] << 16) | ((uint32_t)jr[reflect101(tx0 + c4 + 3, w)] << 24);
+                    *reinterpret_cast<uint32_t *>(&Jt8[y][c4]) = pk;
                 }
                 __syncthreads();
             }
@@ -421,9 +459,12 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
             if (!(iex >= tx0 && iex - tx0 <= 15 && iey >= ty0 && iey - ty0 <= 15)) {
                 tx0 = iex - 8; ty0 = iey - 8;
                 __syncthreads();
-                for (int i = lane; i < 32 * 32; i += 64) {
-                    int y = i >> 5, x = i & 31;
-                    Jt8[y][x] = J[(int64_t)reflect101(ty0 + y, h) * w + reflect101(tx0 + x, w)];
+                for (int i = lane; i < 32 * 8; i += 64) {            // 4 bytes per lane, one dword LDS write
+                    const int y = i >> 3, c4 = (i & 7) * 4;
+                    const uint8_t *jr = J + (int64_t)reflect101(ty0 + y, h) * w;
+                    const uint32_t pk = (uint32_t)jr[reflect101(tx0 + c4, w)] | ((uint32_t)jr[reflect101(tx0 + c4 + 1, w)] << 8) |
+                                        ((uint32_t)jr[reflect101(tx0 + c4 + 2, w)] << 16) | ((uint32_t)jr[reflect101(tx0 + c4 + 3, w)] << 24);
+                    *reinterpret_cast<uint32_t *>(&Jt8[y][c4]) = pk;
                 }
                 __syncthreads();
             }
