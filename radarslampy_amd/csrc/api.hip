@@ -22,7 +22,11 @@ int32_t roam_create(int32_t device_id, roam_ctx **out)
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
     ctx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
+    {   // side stream at the lowest priority: its work (polar peaks) fills the gaps of the latency-bound chain
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
+    }
     *out = ctx;
     return ROAM_OK;
 }
