@@ -172,7 +172,7 @@ hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
     return hipGetLastError();
 }
 
-#define WG_LB 8
+#define WG_LB 16
 #define WG_TW 64          // tile width  (one wavefront = 64 consecutive pixels of a row)
 #define WG_TH 16          // tile height
 #define WG_BOX_ELEMS 4096     // polar samples staged per tile, already decoded to float32 (16 KB)
