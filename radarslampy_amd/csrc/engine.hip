@@ -13,7 +13,6 @@
 // batch dimension is what fills the 256 CUs; within a lane the chain is sequential.
 #include "roam_internal.h"
 #include <new>
-#include <chrono>
 
 #define KS ROAM_MAX_FEATURES
 #define CART_CENTER 1012.0
