@@ -261,10 +261,13 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
         if (t == 0) row_count[b * rows + r] = 0;
         return;
     }
-    // NumPy pairwise sum with 8 lanes per leaf
+    // NumPy pairwise sum with 8 lanes per leaf.  The leaf decomposition depends only on M: it is walked once
+    // per thread and reused for both sums; the tree is combined by one thread and published through LDS
+    // (the kernel is instruction-bound: PMC showed more SALU than VALU instructions, most of them in the
+    // four redundant recursion walks per wavefront of the previous version).
+    int lcnt = 0, my_lo = 0, my_n = -1;
+    PwWalk<4>::select(0, M, t >> 3, lcnt, my_lo, my_n);
     auto np_sum = [&](const float *a) -> float {
-        int lcnt = 0, my_lo = 0, my_n = -1;
-        PwWalk<4>::select(0, M, t >> 3, lcnt, my_lo, my_n);
         const int j = t & 7;
         float res = 0.f;
         if (my_n >= 8) {
@@ -277,17 +280,13 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
             res = rj;
             if (j == 0) for (int i = nn; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);
         } else if (my_n >= 0) {
-            // short leaf (only when M < 8): sequential from 0
-            if (j == 0) for (int i = 0; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);
-            // keep the shuffles convergent
-            (void)__shfl_xor(res, 1);
+            if (j == 0) for (int i = 0; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);   // short leaf (M < 8)
         }
         if (my_n >= 0 && j == 0) leaf_sum[t >> 3] = res;
         __syncthreads();
-        int li = 0;
-        const float tot = PwWalk<4>::combine(leaf_sum, M, li);
+        if (t == 0) { int li = 0; leaf_sum[PK_T / 8 - 1] = PwWalk<4>::combine(leaf_sum, M, li); }
         __syncthreads();
-        return tot;
+        return leaf_sum[PK_T / 8 - 1];
     };
     const float fM = (float)M;
     const float mean = __fdiv_rn(np_sum(ph), fM);
