@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
     ap.add_argument("--kernel-reps", type=int, default=10)
+    ap.add_argument("--h2d", action="store_true", help="stream every scan from pinned host memory over PCIe (double-buffered pool); reports the PCIe-inclusive rate")
     ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
     args = ap.parse_args()
 
@@ -103,6 +104,39 @@ def main():
                 en.synchronize()
 
     s = 0
+    if args.h2d:
+        # PCIe-inclusive mode (f2): one engine, pool = two halves of B slots; lanes of one sequence are contiguous so
+        # that D replicated uploads (host stride 0) feed all lanes; upload(i+1) overlaps step(i) on the copy stream
+        assert E == 1
+        for en in engs:
+            en.close()
+        eng = Engine(B, 2 * B, ctx=ctx, motion_distortion=not args.no_md)
+        engs = [eng]
+        per = B // D
+        pinned = ctx.host_alloc((D * T, 400, 3779))
+        for d in range(D):
+            for t in range(T):
+                pinned[d * T + t] = seqs[d][0][t]
+
+        def upload(step, half):
+            t = 0 if step < 0 else cyc[step % len(cyc)]
+            for d in range(D):
+                n = per if d < D - 1 else B - per * (D - 1)
+                eng.upload_scans_async(half * B + d * per, pinned[d * T + t], n=n, stride=0)
+
+        upload(-1, 0)
+        eng.synchronize()
+        for b in range(B):
+            d = min(b // per, D - 1)
+            eng.init_lane(b, b, seqs[d][2], seqs[d][1][0])
+        upload(0, 1)
+
+        def step_all(i):                                   # noqa: F811
+            half = (i + 1) % 2                             # scans of step i live in half (i+1)%2 (step 0 -> half 1)
+            eng.fence()
+            eng.step(np.arange(B, dtype=np.int32) + half * B)
+            upload(i + 1, i % 2)
+
     for _ in range(args.warmup):
         step_all(s); s += 1
     barrier()
@@ -179,7 +213,7 @@ def main():
             "data": f"synthetic Oxford-format 400x3779 u8 records; {D} distinct seeded sequences x {T} frames per rank, replicated into {B} lane-private HBM copies, ping-pong replay",
             "config": {"workload": "steady-state scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
                                    + ("motion-distortion LM" if not args.no_md else "dead reckoning") + ")",
-                       "lanes_per_gpu": B, "engines_per_gpu": E, "frames": T, "device": info["name"], "arch": info["arch"],
+                       "lanes_per_gpu": B, "engines_per_gpu": E, "h2d_streaming": bool(args.h2d), "frames": T, "device": info["name"], "arch": info["arch"],
                        "initial_features": int(np.mean([len(q[2]) for q in seqs])),
                        "mean_tracked": round(float(np.mean([r["n_tracked"] for r in res])), 1),
                        "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),

@@ -53,6 +53,9 @@ const char *roam_version(void);
 int32_t roam_device_info(roam_ctx *ctx, char *name, int32_t name_cap, int32_t *cu_count,
                          int64_t *hbm_bytes, char *arch, int32_t arch_cap);
 int32_t roam_synchronize(roam_ctx *ctx);
+/* pinned (page-locked) host memory for asynchronous record uploads */
+int32_t roam_host_alloc(roam_ctx *ctx, int64_t bytes, void **out);
+int32_t roam_host_free(roam_ctx *ctx, void *p);
 
 /* ---- a2: getPointCloud.getPointCloudPolarInd (getPointCloud.py:11-54) ------------------
  * polar: rows x cols float32.  out: (cap,2) int32 rows [azimuthIdx, rangeIdx], azimuth-
@@ -168,6 +171,12 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg);
 int32_t roam_engine_destroy(roam_ctx *ctx);
 /* copy one raw record (rows x stride u8) into pool slot idx */
 int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *rec);
+/* raw-record ingest (reference parseData.py:160-226 loads one PNG per frame; here n records of rows x stride u8,
+ * `host_stride` bytes apart in PINNED host memory, are copied to pool slots pool_idx0.. on a copy stream that
+ * overlaps the compute stream).  roam_engine_step waits for every upload enqueued before it;
+ * roam_engine_fence makes later uploads wait for the steps enqueued so far (double-buffered pools). */
+int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t n, const uint8_t *host_records, int64_t host_stride);
+int32_t roam_engine_fence(roam_ctx *ctx);
 /* device-to-device copy of a resident record (lets a benchmark give every lane its own copy of a
  * scan so that input reads are real HBM traffic rather than L2 / Infinity-Cache hits) */
 int32_t roam_engine_copy_scan(roam_ctx *ctx, int32_t dst_idx, int32_t src_idx);

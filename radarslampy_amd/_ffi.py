@@ -42,6 +42,8 @@ _SIGS = {
     "roam_version": (C.c_char_p, []),
     "roam_device_info": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_int32), _P(C.c_int64), C.c_char_p, C.c_int32]),
     "roam_synchronize": (C.c_int32, [_vp]),
+    "roam_host_alloc": (C.c_int32, [_vp, C.c_int64, _P(_vp)]),
+    "roam_host_free": (C.c_int32, [_vp, _vp]),
     "roam_peaks_polar_f32": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
     "roam_peaks_record_u8": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
     "roam_polar_to_cart_f32": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),
@@ -58,6 +60,8 @@ _SIGS = {
     "roam_engine_create": (C.c_int32, [_vp, _P(EngineCfg)]),
     "roam_engine_destroy": (C.c_int32, [_vp]),
     "roam_engine_upload_scan": (C.c_int32, [_vp, C.c_int32, _vp]),
+    "roam_engine_upload_scans_async": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.c_int64]),
+    "roam_engine_fence": (C.c_int32, [_vp]),
     "roam_engine_copy_scan": (C.c_int32, [_vp, C.c_int32, C.c_int32]),
     "roam_engine_init_lane": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
     "roam_engine_step": (C.c_int32, [_vp, _vp]),
@@ -127,6 +131,22 @@ class Context:
         cu, mem = C.c_int32(0), C.c_int64(0)
         self.check(self.lib.roam_device_info(self.h, name, 256, C.byref(cu), C.byref(mem), arch, 64))
         return dict(name=name.value.decode(), arch=arch.value.decode(), cu_count=cu.value, hbm_bytes=mem.value)
+
+    def host_alloc(self, shape, dtype=np.uint8):
+        """numpy array backed by pinned host memory (freed with host_free)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _vp()
+        self.check(self.lib.roam_host_alloc(self.h, n, C.byref(p)))
+        buf = (C.c_uint8 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self.check(self.lib.roam_host_free(self.h, p))
 
     # ---- stage API -------------------------------------------------------------------
     def peaks_polar_f32(self, polar):

@@ -27,6 +27,10 @@ int32_t roam_create(int32_t device_id, roam_ctx **out)
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
         if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, lo) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
     }
+    if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fence, hipEventDisableTiming) != hipSuccess) {
+        delete ctx; return ROAM_E_HIP;
+    }
     *out = ctx;
     return ROAM_OK;
 }
@@ -41,6 +45,9 @@ int32_t roam_destroy(roam_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->scratch) if (s.p) hipFree(s.p);
     hipStreamSynchronize(ctx->stream2);
+    hipStreamSynchronize(ctx->stream3);
+    hipEventDestroy(ctx->ev_up); hipEventDestroy(ctx->ev_fence);
+    hipStreamDestroy(ctx->stream3);
     hipStreamDestroy(ctx->stream2);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -66,7 +73,23 @@ int32_t roam_synchronize(roam_ctx *ctx)
 {
     if (!ctx) return ROAM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream3));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
+int32_t roam_host_alloc(roam_ctx *ctx, int64_t bytes, void **out)
+{
+    if (!ctx || !out || bytes <= 0) return ROAM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return ROAM_OK;
+}
+
+int32_t roam_host_free(roam_ctx *ctx, void *p)
+{
+    if (!ctx) return ROAM_E_ARG;
+    if (p) HIP_TRY(ctx, hipHostFree(p));
     return ROAM_OK;
 }
 

@@ -58,7 +58,7 @@ struct Engine {
     roam_lane_result *results = nullptr;
     hipEvent_t ev[ST_COUNT + 1];
     hipEvent_t ev_fork, ev_join, ev_pk0, ev_pk1;   // side-stream fork / join + its own timing pair
-    bool ev_ok = false, stepped = false;
+    bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
     int kmax() const { int m = 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
     std::vector<void *> allocs;
@@ -407,6 +407,31 @@ int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *
     return ROAM_OK;
 }
 
+// f2 (raw-record ingest): records stream from PINNED host memory on the copy stream while the main
+// stream computes.  Protocol for a double-buffered pool (halves A/B):
+//   roam_engine_upload_scans_async(half B)   - copy stream; starts after the last roam_engine_fence()
+//   roam_engine_step(scans of half A)        - main stream; first waits for every upload enqueued so far
+//   roam_engine_fence()                      - uploads enqueued from now on wait for the steps enqueued so far
+int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t n, const uint8_t *host_records, int64_t host_stride)
+{
+    ENGINE();
+    ARG_CHECK(ctx, host_records && n >= 1 && pool_idx0 >= 0 && pool_idx0 + n <= e->cfg.pool_scans && (host_stride == 0 || host_stride >= (int64_t)e->rec_bytes));
+    for (int i = 0; i < n; i++)
+        HIP_TRY(ctx, hipMemcpyAsync(e->pool + (size_t)(pool_idx0 + i) * e->rec_bytes, host_records + (size_t)i * host_stride, e->rec_bytes,
+                                    hipMemcpyHostToDevice, ctx->stream3));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_up, ctx->stream3));
+    e->uploads_pending = true;
+    return ROAM_OK;
+}
+
+int32_t roam_engine_fence(roam_ctx *ctx)
+{
+    ENGINE();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fence, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fence, 0));
+    return ROAM_OK;
+}
+
 int32_t roam_engine_copy_scan(roam_ctx *ctx, int32_t dst_idx, int32_t src_idx)
 {
     ENGINE();
@@ -471,6 +496,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     const roam_engine_cfg &c = e->cfg;
     const int nw = KS / 64;
     const int KM = e->kmax();          // host-known bound: feature counts only shrink between (re)seeds
+    if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_up, 0)); e->uploads_pending = false; }
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx, scan_idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, st));
     uint8_t *prev = e->pyr[e->cur], *next = e->pyr[e->cur ^ 1];
 

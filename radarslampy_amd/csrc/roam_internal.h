@@ -26,6 +26,8 @@ struct roam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: work that is independent of the tracking chain (polar peaks)
+    hipStream_t stream3 = nullptr;     // copy stream: asynchronous record uploads from pinned host memory
+    hipEvent_t ev_up = nullptr, ev_fence = nullptr;
     char err[512] = {0};
     // growable scratch buffers for the stage API (indexed by role)
     DevBuf scratch[24];

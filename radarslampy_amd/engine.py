@@ -35,6 +35,16 @@ class Engine:
         assert rec.shape == (self.rows, self.stride), rec.shape
         self.ctx.check(self.lib.roam_engine_upload_scan(self.ctx.h, int(pool_idx), _ffi._ptr(rec)))
 
+    def upload_scans_async(self, pool_idx0: int, pinned_records: np.ndarray, n: int = None, stride: int = None):
+        """asynchronous upload of n records from PINNED host memory (Context.host_alloc) on the copy stream"""
+        rec_bytes = self.rows * self.stride
+        n = pinned_records.size // rec_bytes if n is None else n
+        stride = rec_bytes if stride is None else stride
+        self.ctx.check(self.lib.roam_engine_upload_scans_async(self.ctx.h, int(pool_idx0), int(n), _ffi._ptr(pinned_records), int(stride)))
+
+    def fence(self):
+        self.ctx.check(self.lib.roam_engine_fence(self.ctx.h))
+
     def copy_scan(self, dst_idx: int, src_idx: int):
         self.ctx.check(self.lib.roam_engine_copy_scan(self.ctx.h, int(dst_idx), int(src_idx)))
 
