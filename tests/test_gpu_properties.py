@@ -110,3 +110,19 @@ def test_engine_lanes_are_independent_and_deterministic():
         assert np.array_equal(solo.results()[0]["pose"], out[i][0]["pose"])
     eng.close()
     ctx.close()
+
+
+def test_peaks_u8_ragged_clips(ctx):
+    """register-based u8 row kernel (clip <= 2048) and the generic kernel (clip > 2048) across awkward widths,
+    payload offsets and row counts, with plateaus, saturated runs and empty rows"""
+    rng = np.random.default_rng(17)
+    for rows, clip, off in [(1, 3, 0), (2, 8, 1), (3, 9, 11), (5, 63, 2), (4, 64, 11), (4, 65, 0), (7, 1000, 11), (3, 2047, 5),
+                            (3, 2048, 11), (2, 2049, 11), (2, 3768, 11)]:
+        stride = off + clip + int(rng.integers(0, 7))
+        rec = rng.integers(0, 6, size=(rows, stride), dtype=np.uint8) * 40       # few levels -> many plateaus
+        rec[0, off:off + clip] = 255                                              # saturated row
+        if rows > 1:
+            rec[1, off:off + clip] = 0                                            # empty row
+        got = ctx.peaks_record_u8(rec, payload_off=off, clip=clip)
+        want = oracle.peaks_from_record_u8(rec, off, clip)
+        assert np.array_equal(got, want), (rows, clip, off)
