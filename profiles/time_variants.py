@@ -1,0 +1,21 @@
+"""time the warp kernel of several builds of the library (ablation helper): python profiles/time_variants.py a.so b.so ..."""
+import sys, subprocess, os
+sys.path.insert(0, '.')
+if len(sys.argv) > 2:
+    for lib in sys.argv[1:]:
+        subprocess.run([sys.executable, __file__, lib])
+    sys.exit(0)
+from radarslampy_amd import _ffi
+_ffi.LIB_PATH = os.path.abspath(sys.argv[1])
+import numpy as np
+from radarslampy_amd import synth
+from radarslampy_amd.engine import Engine
+ctx = _ffi.Context(0)
+B = 256; T = 3
+recs, poses, feat = synth.make_sequence(5, T, n_movers=16, distortion=True)
+eng = Engine(B, T, ctx=ctx)
+for t in range(T): eng.upload_scan(t, recs[t])
+for b in range(B): eng.init_lane(b, 0, feat, poses[0])
+eng.step(np.full(B, 1, np.int32)); eng.synchronize()
+ms, by = eng.time_kernel("warp_quantise", 10)
+print(os.path.basename(sys.argv[1]), "warp_quantise", round(ms, 4), 'ms', round(by / ms / 1e6, 1), 'GB/s')

@@ -172,31 +172,89 @@ hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
     return hipGetLastError();
 }
 
-#define WG_LB 16
+#ifndef WG_LB
+#define WG_LB 32         // scans of the batch per workgroup (amortises the map read and the weights)
+#endif
 #define WG_TW 64          // tile width  (one wavefront = 64 consecutive pixels of a row)
 #define WG_TH 16          // tile height
-#define WG_BOX_ELEMS 4096     // polar samples staged per tile, already decoded to float32 (16 KB)
+#define WG_BOX_ELEMS 4096     // polar samples staged per pass, already decoded to float32 (16 KB)
+#ifndef WG_FILL_U
+#define WG_FILL_U 4
+#endif
+//          // independent row loads in flight per wavefront during the fill
 // 256-thread block = 64 x 16 pixel tile; wave w owns rows 4w..4w+3, lane = x offset.
-// The polar footprint of a tile is a small box (range span x azimuth span): it is staged in
-// LDS with coalesced row loads (one wavefront per polar row, 64 consecutive bytes per load) and
-// the 4 bilinear taps per pixel become LDS byte reads - the PMC profile of the direct-gather
-// version showed 28 L1 accesses per wave-level load and the texture addresser 63 % busy.
-// Tiles whose footprint does not fit (next to the image centre, or straddling the 0/2pi seam)
-// fall back to direct L1/L2 gathers; tiles beyond the maximum range write zeros.  Results are
-// transposed through a 1 KB LDS tile so that the global stores are whole dwords.
+// The polar footprint of a tile is a small box (range span x azimuth span; median 310 samples,
+// 52 x 7): it is staged in LDS with coalesced row loads (one wavefront per polar row, up to 64
+// consecutive bytes per load) and the 4 bilinear taps per pixel become LDS reads - the PMC
+// profile of the direct-gather version showed 28 L1 accesses per wave-level load and the texture
+// addresser 63 % busy.  Because the box is small, the boxes of SEVERAL scans of the batch
+// (WG_BOX_ELEMS / box size, up to WG_LB) are staged in one pass: the fill issues WG_FILL_U
+// independent row loads per wavefront before the first one is consumed, and a pass costs two
+// barriers whatever the number of scans it covers.  Tiles whose footprint does not fit (next to
+// the image centre, or straddling the 0/2pi seam) fall back to direct L1/L2 gathers; tiles
+// beyond the maximum range write zeros.  A thread's 4 results (4 rows of one column) are
+// transposed against its 3 quad neighbours with DPP quad broadcasts + v_perm_b32, so that every
+// thread stores one whole dword of one row without going through LDS.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int M> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, M * 0x55, 0xf, 0xf, true);
+}
+
+// stage the polar box of U consecutive scans (l, l+1, ...): wave wvs takes rows wvs, wvs+4, ...
+template <int U>
+__device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t lane_stride,
+                                         const int32_t *__restrict__ lane_index, int l, int64_t row_stride, int rows,
+                                         int cols, int mnx, int mny, int bw, int bh, int elems, int wvs, int lane,
+                                         float *__restrict__ bq)
+{
+    int64_t so[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) so[u] = (lane_index ? (int64_t)lane_index[l + u] : (int64_t)(l + u)) * lane_stride;
+    for (int k = wvs; k < bh; k += 4) {
+        int r = mny + k - 1;
+        if (r < 0) r += rows; else if (r >= rows) r -= rows;
+        for (int cb = 0; cb < bw; cb += 64) {
+            const int c = min(cb + lane, bw - 1);         // clamped lanes rewrite the last column
+            const bool inr = mnx + c < cols;
+            const uint8_t *srow = sp + ((int64_t)r * row_stride + min(mnx + c, cols - 1));
+            float *drow = bq + (k * bw + c);
+            uint32_t raw[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) raw[u] = srow[so[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) drow[u * elems] = inr ? code_to_f32(raw[u]) : 0.f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__restrict__ map, const uint8_t *__restrict__ pool,
                                                           int64_t lane_stride, int64_t row_stride, int payload_off,
                                                           const int32_t *__restrict__ lane_index, int B, int rows,
                                                           int cols, int W, uint8_t *__restrict__ cart_u8,
-                                                          int64_t u8_lane_stride)
+                                                          int64_t u8_lane_stride, int gx, int gy, int total)
 {
-    __shared__ __align__(16) uint8_t tile[WG_TH][WG_TW];
     __shared__ __align__(16) float box[WG_BOX_ELEMS];
     __shared__ int red[4][4];
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
+    // L2), so XCD x is given the x-th contiguous eighth of the (scan group, tile row, tile) list:
+    // the polar rows one scan group needs are then fetched into ONE L2 instead of all eight.
+    const int per_xcd = (total + 7) >> 3;
+    const int vid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (vid >= total) return;
+    const int bz = vid / (gx * gy), brem = vid - bz * (gx * gy);
+    const int by = brem / gx, bx_ = brem - by * gx;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * WG_TW + lane;
-    const int y0 = blockIdx.y * WG_TH;
+    const int x = bx_ * WG_TW + lane;
+    const int y0 = by * WG_TH;
     const bool xin = x < W;
+    const int l0 = bz * WG_LB, l1 = min(B, l0 + WG_LB);
+    // scan -> byte offset of its payload; the argument is wave-uniform, so this is scalar code
+    auto src_off = [&](int l) -> int64_t {
+        const int64_t sel = lane_index ? (int64_t)lane_index[l] : (int64_t)l;
+        return sel * lane_stride + payload_off;
+    };
     int ixv[4], iyv[4];
     float w00[4], w01[4], w10[4], w11[4];
     bool in0[4];
@@ -226,9 +284,13 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     for (int k = 0; k < 4; k++) {
         mnx = min(mnx, red[k][0]); mxx = max(mxx, red[k][1]); mny = min(mny, red[k][2]); mxy = max(mxy, red[k][3]);
     }
+    // the box is the same for the whole workgroup: keep it in scalar registers
+    mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);
+    mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
     const bool any = mxx >= 0;
     const int bw = mxx - mnx + 2, bh = mxy - mny + 2;
-    const bool use_box = any && (bw * bh <= WG_BOX_ELEMS);
+    const int elems = bw * bh;
+    const bool use_box = any && (elems <= WG_BOX_ELEMS);
     int off0[4], off1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -241,51 +303,94 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             off1[j] = r1 * (int)row_stride + ixv[j];
         }
     }
-    // dword owned by this thread in the store phase
-    const int srow = threadIdx.x >> 4, scol = (threadIdx.x & 15) * 4;
-    const int sy = y0 + srow, sx = blockIdx.x * WG_TW + scol;
+    // after the quad transpose lane 4g+i holds row 4*wv+i, columns 4g..4g+3 of the tile; one
+    // ds_bpermute then moves that dword to lane 16*i+g so that 16 consecutive lanes store 64
+    // consecutive bytes of one row
+    const int qi = lane & 3;
+    const int pull = ((lane & 15) << 2) | (lane >> 4);
+    const int sy = y0 + wv * 4 + (lane >> 4), sx = bx_ * WG_TW + ((lane & 15) << 2);
     const bool sok = sy < W && sx + 3 < W;
-    const int l0 = blockIdx.z * WG_LB, l1 = min(B, l0 + WG_LB);
-    for (int l = l0; l < l1; l++) {
-        if (!any) {                                   // beyond the maximum range: zeros
-            if (sok) *reinterpret_cast<uint32_t *>(cart_u8 + (int64_t)l * u8_lane_stride + (int64_t)sy * W + sx) = 0u;
-            continue;
-        }
-        const int64_t sel = lane_index ? (int64_t)lane_index[l] : (int64_t)l;
-        const uint8_t *p = pool + sel * lane_stride + payload_off;
-        if (use_box) {
-            for (int k = wv; k < bh; k += 4) {        // one wavefront per polar row of the box
-                int r = mny + k - 1;
-                if (r < 0) r += rows; else if (r >= rows) r -= rows;
-                const uint8_t *src = p + (int64_t)r * row_stride + mnx;
-                for (int c = lane; c < bw; c += 64) box[k * bw + c] = (mnx + c < cols) ? code_to_f32(src[c]) : 0.f;
-            }
-            __syncthreads();
-        }
+    const uint32_t psel = 0x0c0c0000u | (uint32_t)qi | ((uint32_t)(4 + qi) << 8);
+    uint8_t *dst = cart_u8 + (int64_t)sy * W + sx;
+    if (!any) {                                       // beyond the maximum range: zeros
+        if (sok)
+            for (int l = l0; l < l1; l++) *reinterpret_cast<uint32_t *>(dst + (int64_t)l * u8_lane_stride) = 0u;
+        return;
+    }
+    if (!use_box) {                                   // rare tiles: direct gathers, one scan at a time
+        for (int l = l0; l < l1; l++) {
+            const uint8_t *p = pool + src_off(l);
+            uint32_t pk = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v = 0.f;
-            if (in0[j]) {
-                float s00, s01, s10, s11;
-                if (use_box) {
-                    s00 = box[off0[j]]; s01 = box[off0[j] + 1];
-                    s10 = box[off1[j]]; s11 = box[off1[j] + 1];
-                } else {
+            for (int j = 0; j < 4; j++) {
+                float v = 0.f;
+                if (in0[j]) {
                     const bool i1 = ixv[j] + 1 < cols;
-                    s00 = code_to_f32(p[off0[j]]); s01 = i1 ? code_to_f32(p[off0[j] + 1]) : 0.f;
-                    s10 = code_to_f32(p[off1[j]]); s11 = i1 ? code_to_f32(p[off1[j] + 1]) : 0.f;
+                    const float s00 = code_to_f32(p[off0[j]]), s01 = i1 ? code_to_f32(p[off0[j] + 1]) : 0.f;
+                    const float s10 = code_to_f32(p[off1[j]]), s11 = i1 ? code_to_f32(p[off1[j] + 1]) : 0.f;
+                    v = __fmul_rn(s00, w00[j]);
+                    v = __fadd_rn(v, __fmul_rn(s01, w01[j]));
+                    v = __fadd_rn(v, __fmul_rn(s10, w10[j]));
+                    v = __fadd_rn(v, __fmul_rn(s11, w11[j]));
                 }
-                v = __fmul_rn(s00, w00[j]);
-                v = __fadd_rn(v, __fmul_rn(s01, w01[j]));
-                v = __fadd_rn(v, __fmul_rn(s10, w10[j]));
-                v = __fadd_rn(v, __fmul_rn(s11, w11[j]));
+                pk |= quant_u8(v) << (8 * j);
             }
-            tile[wv * 4 + j][lane] = (uint8_t)quant_u8(v);
+            const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
+            const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));
+            if (sok) *reinterpret_cast<uint32_t *>(dst + (int64_t)l * u8_lane_stride) = o;
+        }
+        return;
+    }
+    // box path, written branch-free: pixels outside the scan get zero weights and offset 0, loads
+    // past the end of a row / past the last scan of the pass are clamped onto a valid duplicate
+    f32x2 wa[4], wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!in0[j]) { w00[j] = w01[j] = w10[j] = w11[j] = 0.f; off0[j] = off1[j] = 0; }
+        wa[j] = f32x2{w00[j], w01[j]};
+        wb[j] = f32x2{w10[j], w11[j]};
+    }
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const int per = max(1, min(WG_LB, WG_BOX_ELEMS / elems));
+    for (int lb = l0; lb < l1; lb += per) {
+        const int nq = min(per, l1 - lb);
+        // wave w stages polar rows w, w+4, ... of the box for up to WG_FILL_U scans at a time:
+        // their loads (same row, same columns) are issued before the first is consumed
+        for (int qb = 0; qb < nq;) {
+            const int rem = nq - qb;
+            const uint8_t *sp = pool + payload_off;
+            float *bq = box + qb * elems;
+            if (rem >= 8 && WG_FILL_U >= 8) { box_fill<8>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 8; }
+            else if (rem >= 4 && WG_FILL_U >= 4) { box_fill<4>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 4; }
+            else if (rem >= 2 && WG_FILL_U >= 2) { box_fill<2>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 2; }
+            else { box_fill<1>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 1; }
         }
         __syncthreads();
-        if (sok)
-            *reinterpret_cast<uint32_t *>(cart_u8 + (int64_t)l * u8_lane_stride + (int64_t)sy * W + sx) =
-                *reinterpret_cast<const uint32_t *>(&tile[srow][scol]);
+        for (int q = 0; q < nq; q++) {
+            const float *bx = box + q * elems;
+            f32x2 ta[4], tb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ta[j] = f32x2{bx[off0[j]], bx[off0[j] + 1]};      // (s00, s01): one ds_read2_b32 (4-byte aligned)
+                tb[j] = f32x2{bx[off1[j]], bx[off1[j] + 1]};      // (s10, s11)
+            }
+            // the products are formed two at a time (v_pk_mul_f32: IEEE multiplies, no fusion); the
+            // sums keep the reference order ((s00 w00 + s01 w01) + s10 w10) + s11 w11
+            float vq[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x2 pa = ta[j] * wa[j], pb = tb[j] * wb[j];
+                vq[j] = __fadd_rn(__fadd_rn(__fadd_rn(pa.x, pa.y), pb.x), pb.y);
+            }
+            const f32x2 q01 = f32x2{vq[0], vq[1]} * 255.f, q23 = f32x2{vq[2], vq[3]} * 255.f;
+            const uint32_t pk = (uint32_t)(int)q01.x | ((uint32_t)(int)q01.y << 8) | ((uint32_t)(int)q23.x << 16) |
+                                ((uint32_t)(int)q23.y << 24);
+            const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
+            const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));
+            if (sok) *reinterpret_cast<uint32_t *>(dst + (int64_t)(lb + q) * u8_lane_stride) = o;
+        }
         __syncthreads();
     }
 }
@@ -295,10 +400,13 @@ hipError_t launch_warp_gather(hipStream_t st, const uint32_t *map, WarpSrc src, 
                               uint8_t *cart_u8, int64_t u8_lane_stride)
 {
     const int R = cols / 2, W = 2 * R;
-    dim3 grid((W + WG_TW - 1) / WG_TW, (W + WG_TH - 1) / WG_TH, (B + WG_LB - 1) / WG_LB);
-    hipLaunchKernelGGL(warp_gather_kernel, grid, dim3(256), 0, st, map, reinterpret_cast<const uint8_t *>(src.base),
+    const int gx = (W + WG_TW - 1) / WG_TW, gy = (W + WG_TH - 1) / WG_TH, gz = (B + WG_LB - 1) / WG_LB;
+    const int64_t total = (int64_t)gx * gy * gz;
+    if (total > 0x7ffffff0) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)(((total + 7) >> 3) << 3);
+    hipLaunchKernelGGL(warp_gather_kernel, dim3(blocks), dim3(256), 0, st, map, reinterpret_cast<const uint8_t *>(src.base),
                        src.lane_stride, src.row_stride, src.payload_off, src.lane_index, B, rows, cols, W, cart_u8,
-                       u8_lane_stride);
+                       u8_lane_stride, gx, gy, (int)total);
     return hipGetLastError();
 }
 
