@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
                 uint32_t *hrow = hb[i % 5];
                 for (int q = t; q < npair; q += 256) {
                     const uint32_t d0 = rowbuf[q], d1 = rowbuf[q + 1], d2 = rowbuf[q + 2];
-                    const int b2 = (d0 >> 16) & 255, b3 = d0 >> 24, b4 = d1 & 255, b5 = (d1 >> 8) & 255, b6 = (d1 >> 16) & 255,
-                              b7 = d1 >> 24, b8 = d2 & 255;
-                    hrow[q] = (uint32_t)(b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6) | ((uint32_t)(b4 + 4 * b5 + 6 * b6 + 4 * b7 + b8) << 16);
+                    // bytes b0..b3 = d0, b4..b7 = d1, b8.. = d2; left output = b2+4b3+6b4+4b5+b6, right = b4+4b5+6b6+4b7+b8
+                    const uint32_t mid = __builtin_amdgcn_alignbyte(d1, d0, 2);                  // b2 b3 b4 b5
+                    const uint32_t lo = __builtin_amdgcn_udot4(d1, 0x00010000u, __builtin_amdgcn_udot4(mid, 0x04060401u, 0u, false), false);
+                    const uint32_t hi = __builtin_amdgcn_udot4(d2, 0x00000001u, __builtin_amdgcn_udot4(d1, 0x04060401u, 0u, false), false);
+                    hrow[q] = lo | (hi << 16);
                 }
                 __syncthreads();
                 if (i >= 4 && !(i & 1)) {
@@ -181,10 +183,11 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
                     const uint32_t *r0 = hb[(i - 4) % 5], *r1 = hb[(i - 3) % 5], *r2 = hb[(i - 2) % 5], *r3 = hb[(i - 1) % 5], *r4 = hb[i % 5];
                     uint16_t *orow = reinterpret_cast<uint16_t *>(d + (int64_t)(oy0 + ko) * dw);
                     for (int q = t; q < npair; q += 256) {
+                        // two u16 column sums per dword; 16 * 16 * 255 + 128 < 65536, so the halves never carry
+                        // into each other and the 5-tap sum is plain 32-bit arithmetic on the packed pair
                         const uint32_t v0 = r0[q], v1 = r1[q], v2 = r2[q], v3 = r3[q], v4 = r4[q];
-                        const uint32_t lo = (v0 & 0xffff) + 4 * (v1 & 0xffff) + 6 * (v2 & 0xffff) + 4 * (v3 & 0xffff) + (v4 & 0xffff);
-                        const uint32_t hi = (v0 >> 16) + 4 * (v1 >> 16) + 6 * (v2 >> 16) + 4 * (v3 >> 16) + (v4 >> 16);
-                        orow[q] = (uint16_t)(((lo + 128) >> 8) | (((hi + 128) >> 8) << 8));
+                        const uint32_t sum = (v0 + v4) + 4u * (v1 + v3) + 6u * v2 + 0x00800080u;
+                        orow[q] = (uint16_t)__builtin_amdgcn_perm(0u, sum, 0x0c0c0301u);       // (lo >> 8) | ((hi >> 8) << 8)
                     }
                 }
             }
