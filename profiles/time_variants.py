@@ -17,5 +17,6 @@ eng = Engine(B, T, ctx=ctx)
 for t in range(T): eng.upload_scan(t, recs[t])
 for b in range(B): eng.init_lane(b, 0, feat, poses[0])
 eng.step(np.full(B, 1, np.int32)); eng.synchronize()
-ms, by = eng.time_kernel("warp_quantise", 10)
-print(os.path.basename(sys.argv[1]), "warp_quantise", round(ms, 4), 'ms', round(by / ms / 1e6, 1), 'GB/s')
+for name in os.environ.get("KERNELS", "warp_quantise").split(","):
+    ms, by = eng.time_kernel(name, 10)
+    print(os.path.basename(sys.argv[1]), name, round(ms, 4), 'ms', round(by / ms / 1e6, 1), 'GB/s')

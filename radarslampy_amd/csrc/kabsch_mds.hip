@@ -108,6 +108,22 @@ __device__ __forceinline__ double wrap_pi(double a)
     return r - M_PI;
 }
 
+// the three velocity-prior residuals of error_vector for parameters x (ct, st = cos / sin of x[5])
+__device__ __forceinline__ void mds_vel_resid(const LmShared *S, const double *x, double ct, double st, double *out3)
+{
+    const double tx = x[3], ty = x[4];
+    const double *I = S->T0inv;
+    const double m00 = I[0] * ct + I[1] * st, m10 = I[3] * ct + I[4] * st;
+    const double mdx = I[0] * tx + I[1] * ty + I[2], mdy = I[3] * tx + I[4] * ty + I[5];
+    const double dth = atan2(m10, m00);
+    const double d0 = x[0] - mdx / S->period, d1 = x[1] - mdy / S->period;
+    const double d2 = wrap_pi(x[2] - dth / S->period);
+    const double Nn = (double)S->N;
+    out3[0] = S->info_v[0] * (d0 * Nn);
+    out3[1] = S->info_v[1] * (d1 * Nn);
+    out3[2] = S->info_v[2] * (d2 * Nn);
+}
+
 // error_vector (motionDistortion.py:162-205).  Thread t owns points t, t+256, ...; thread 0
 // also owns the three velocity residuals.  No barrier inside.
 __device__ void mds_resid(const LmShared *S, const double *x, const double *p_w, const double *p_jt,
@@ -130,21 +146,82 @@ __device__ void mds_resid(const LmShared *S, const double *x, const double *p_w,
         f[2 * i] = S->info_p[0] * log(nx * nx / 2 + 1);
         f[2 * i + 1] = S->info_p[1] * log(ny * ny / 2 + 1);
     }
-    if (threadIdx.x == 0) {
-        const double *I = S->T0inv;
-        const double m00 = I[0] * ct + I[1] * st, m10 = I[3] * ct + I[4] * st;
-        const double mdx = I[0] * tx + I[1] * ty + I[2], mdy = I[3] * tx + I[4] * ty + I[5];
-        const double dth = atan2(m10, m00);
-        const double d0 = x[0] - mdx / S->period, d1 = x[1] - mdy / S->period;
-        const double d2 = wrap_pi(x[2] - dth / S->period);
-        const double Nn = (double)N;
-        f[2 * N] = S->info_v[0] * (d0 * Nn);
-        f[2 * N + 1] = S->info_v[1] * (d1 * Nn);
-        f[2 * N + 2] = S->info_v[2] * (d2 * Nn);
-    }
+    if (threadIdx.x == 0) mds_vel_resid(S, x, ct, st, f + 2 * N);
 }
 
 #define A_(i, j) a[(size_t)(j) * m + (i)]
+
+// fdjac2 for error_vector: the six forward-difference columns (x[j] -> xp[j] = x[j] + h[j]) of the rows
+// this thread owns.  Every column repeats the operations mds_resid would perform on the perturbed vector,
+// but subexpressions a perturbation leaves untouched are evaluated once (cos/sin of the rotation angles,
+// the rotated points, ...) - same operations on the same operands, so the quotients are bit-identical to
+// six full evaluations, and a component a parameter does not enter differences to exactly +0.  The
+// transcendental count per point drops from 6 sincos + 12 log to 2 sincos + 10 log, and the ten logs are
+// independent (the solve is latency-bound).  Thread blockDim-1-j also takes the velocity rows of column j.
+__device__ void mds_jac(const LmShared *S, const double *x, const double *xp, const double *h, const double *p_w,
+                        const double *p_jt, const double *dT, const double *fvec, double *a, int m)
+{
+    const int N = S->N;
+    const double tx = x[3], ty = x[4];
+    const double ct0 = cos(x[5]), st0 = sin(x[5]);
+    const double ct5 = cos(xp[5]), st5 = sin(xp[5]);
+    const double ip0 = S->info_p[0], ip1 = S->info_p[1];
+    for (int i = threadIdx.x; i < N; i += (int)blockDim.x) {
+        const double d = dT[i];
+        const double px = p_jt[2 * i], py = p_jt[2 * i + 1];
+        const double pwx = p_w[2 * i], pwy = p_w[2 * i + 1];
+        const double f0x = fvec[2 * i], f0y = fvec[2 * i + 1];
+        const double a0 = x[2] * d, a2 = xp[2] * d;
+        const double ca0 = cos(a0), sa0 = sin(a0), ca2 = cos(a2), sa2 = sin(a2);
+        const double rx0 = ca0 * px - sa0 * py, ry0 = sa0 * px + ca0 * py;
+        const double ux0 = rx0 + x[0] * d, uy0 = ry0 + x[1] * d;
+        const double wx0 = pwx - tx, wy0 = pwy - ty;
+        const double ex0 = ct0 * wx0 + st0 * wy0, ey0 = -st0 * wx0 + ct0 * wy0;
+        double nx, ny;
+        // column 0 (v_x): only the x component moves
+        nx = ex0 - (rx0 + xp[0] * d);
+        A_(2 * i, 0) = (ip0 * log(nx * nx / 2 + 1) - f0x) / h[0];
+        A_(2 * i + 1, 0) = 0.0;
+        // column 1 (v_y)
+        ny = ey0 - (ry0 + xp[1] * d);
+        A_(2 * i, 1) = 0.0;
+        A_(2 * i + 1, 1) = (ip1 * log(ny * ny / 2 + 1) - f0y) / h[1];
+        // column 2 (omega)
+        nx = ex0 - ((ca2 * px - sa2 * py) + x[0] * d);
+        ny = ey0 - ((sa2 * px + ca2 * py) + x[1] * d);
+        A_(2 * i, 2) = (ip0 * log(nx * nx / 2 + 1) - f0x) / h[2];
+        A_(2 * i + 1, 2) = (ip1 * log(ny * ny / 2 + 1) - f0y) / h[2];
+        // column 3 (t_x)
+        {
+            const double wx = pwx - xp[3];
+            nx = (ct0 * wx + st0 * wy0) - ux0;
+            ny = (-st0 * wx + ct0 * wy0) - uy0;
+            A_(2 * i, 3) = (ip0 * log(nx * nx / 2 + 1) - f0x) / h[3];
+            A_(2 * i + 1, 3) = (ip1 * log(ny * ny / 2 + 1) - f0y) / h[3];
+        }
+        // column 4 (t_y)
+        {
+            const double wy = pwy - xp[4];
+            nx = (ct0 * wx0 + st0 * wy) - ux0;
+            ny = (-st0 * wx0 + ct0 * wy) - uy0;
+            A_(2 * i, 4) = (ip0 * log(nx * nx / 2 + 1) - f0x) / h[4];
+            A_(2 * i + 1, 4) = (ip1 * log(ny * ny / 2 + 1) - f0y) / h[4];
+        }
+        // column 5 (theta)
+        nx = (ct5 * wx0 + st5 * wy0) - ux0;
+        ny = (-st5 * wx0 + ct5 * wy0) - uy0;
+        A_(2 * i, 5) = (ip0 * log(nx * nx / 2 + 1) - f0x) / h[5];
+        A_(2 * i + 1, 5) = (ip1 * log(ny * ny / 2 + 1) - f0y) / h[5];
+    }
+    const int jv = (int)blockDim.x - 1 - (int)threadIdx.x;      // velocity rows of column jv
+    if (jv < 6) {
+        double xv[6], out3[3];
+#pragma unroll
+        for (int k = 0; k < 6; k++) xv[k] = (k == jv) ? xp[k] : x[k];
+        mds_vel_resid(S, xv, jv == 5 ? ct5 : ct0, jv == 5 ? st5 : st0, out3);
+        for (int k = 0; k < 3; k++) A_(2 * N + k, jv) = (out3[k] - fvec[2 * N + k]) / h[jv];
+    }
+}
 
 // serial 6x6 pieces (thread 0 only), operating on the first 6 rows of `a`
 __device__ void qrsolv6(int m, double *a, const int *ipvt, const double *diag, const double *qtb,
@@ -340,19 +417,15 @@ __global__ __launch_bounds__(LM_TMAX) void mds_lm_kernel(MdsProblemDesc P, doubl
         // between the perturbed evaluation and the difference quotient)
 #pragma unroll
         for (int j = 0; j < 6; j++) xl[j] = S.x[j];
-        for (int j = 0; j < n; j++) {
-            const double temp = xl[j];
-            double h = eps * fabs(temp);
+        double xp[6], hh[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double h = eps * fabs(xl[j]);
             if (h == 0) h = eps;
-            xl[j] = temp + h;
-            mds_resid(&S, xl, p_w, p_jt, dT, wf);
-            xl[j] = temp;
-            for (int i = t; i < N; i += (int)blockDim.x) {
-                A_(2 * i, j) = (wf[2 * i] - fvec[2 * i]) / h;
-                A_(2 * i + 1, j) = (wf[2 * i + 1] - fvec[2 * i + 1]) / h;
-            }
-            if (t == 0) for (int i = 2 * N; i < m; i++) A_(i, j) = (wf[i] - fvec[i]) / h;
+            hh[j] = h;
+            xp[j] = xl[j] + h;
         }
+        mds_jac(&S, xl, xp, hh, p_w, p_jt, dT, fvec, a, m);
         __syncthreads();
         // ---- qrfac with column pivoting
         for (int j = 0; j < n; j++) {

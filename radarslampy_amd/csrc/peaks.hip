@@ -207,6 +207,7 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
 // NumPy-order leaf sums use 8 lanes per leaf (one per accumulator, combined by a 3-step butterfly
 // that reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) exactly), at most 4 candidates per thread.
 #define PKF_MAXC 2048
+typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
 __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int rows, int cols,
                                                              uint16_t *__restrict__ row_stage, int stage_cap,
                                                              int32_t *__restrict__ row_count)
@@ -222,9 +223,16 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
                        (int64_t)r * src.row_stride + src.payload_off;
     const int base = t * 8;
     uint32_t v[8];
+    if (base + 7 < cols) {
+        // one 8-byte load per thread: record rows are not dword aligned (stride 3779, payload at +11);
+        // the hardware handles the misaligned access, eight byte loads cost eight trips through the TA
+        const u32x2_a1 wv = *reinterpret_cast<const u32x2_a1 *>(p + base);
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (base + j < cols) ? (uint32_t)p[base + j] : 0u;
-    {
+        for (int j = 0; j < 4; j++) { v[j] = (wv.x >> (8 * j)) & 255u; v[4 + j] = (wv.y >> (8 * j)) & 255u; }
+        *reinterpret_cast<uint2 *>(&xb[base]) = make_uint2(wv.x, wv.y);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (base + j < cols) ? (uint32_t)p[base + j] : 0u;
         const uint32_t w0 = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
         const uint32_t w1 = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
         *reinterpret_cast<uint2 *>(&xb[base]) = make_uint2(w0, w1);
@@ -253,10 +261,18 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
     for (int j = 0; j < 8; j++) { mids[j] = peak_mid(j); cnt += mids[j] >= 0; }
     int M;
     int pos = block_excl_scan(cnt, scan_sh, &M);
+#if defined(PK_ABL) && PK_ABL == 1
+    if (t == 0) row_count[b * rows + r] = M & 1;
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; j++)
         if (mids[j] >= 0) { ph[pos] = code_to_f32_pk(v[j]); pm[pos] = (uint16_t)mids[j]; pos++; }
     __syncthreads();
+#if defined(PK_ABL) && PK_ABL == 2
+    if (t == 0) row_count[b * rows + r] = (int)ph[M / 2] & 1;
+    return;
+#endif
     if (M == 0) {
         if (t == 0) row_count[b * rows + r] = 0;
         return;
@@ -295,6 +311,10 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
         sq[k] = __fmul_rn(d, d);
     }
     __syncthreads();
+#if defined(PK_ABL) && PK_ABL == 3
+    if (t == 0) row_count[b * rows + r] = (int)mean & 1;
+    return;
+#endif
     const float var = __fdiv_rn(np_sum(sq), fM);
     const float thr = __fadd_rn(mean, rn_sqrtf(var));
     // threshold + ordered compaction: 4 consecutive candidates per thread (M <= 1024)
