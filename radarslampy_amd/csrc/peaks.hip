@@ -261,18 +261,10 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
     for (int j = 0; j < 8; j++) { mids[j] = peak_mid(j); cnt += mids[j] >= 0; }
     int M;
     int pos = block_excl_scan(cnt, scan_sh, &M);
-#if defined(PK_ABL) && PK_ABL == 1
-    if (t == 0) row_count[b * rows + r] = M & 1;
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < 8; j++)
         if (mids[j] >= 0) { ph[pos] = code_to_f32_pk(v[j]); pm[pos] = (uint16_t)mids[j]; pos++; }
     __syncthreads();
-#if defined(PK_ABL) && PK_ABL == 2
-    if (t == 0) row_count[b * rows + r] = (int)ph[M / 2] & 1;
-    return;
-#endif
     if (M == 0) {
         if (t == 0) row_count[b * rows + r] = 0;
         return;
@@ -311,10 +303,6 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
         sq[k] = __fmul_rn(d, d);
     }
     __syncthreads();
-#if defined(PK_ABL) && PK_ABL == 3
-    if (t == 0) row_count[b * rows + r] = (int)mean & 1;
-    return;
-#endif
     const float var = __fdiv_rn(np_sum(sq), fM);
     const float thr = __fadd_rn(mean, rn_sqrtf(var));
     // threshold + ordered compaction: 4 consecutive candidates per thread (M <= 1024)
@@ -329,6 +317,183 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int ro
     for (int q = 0; q < 4; q++)
         if (keep[q]) { if (p2 < stage_cap) dst[p2] = pm[t * 4 + q]; p2++; }
     if (t == 0) row_count[b * rows + r] = total;
+}
+
+// ---- one wavefront per azimuth row (u8 records, cols <= 2048): no workgroup barrier anywhere.
+// The 256-thread version above spends its time in instruction issue (PMC: more SALU than VALU
+// instructions - eight divergent plateau tests per thread, two block scans, a dozen barriers for
+// 2 KB of data).  Here a lane owns 32 consecutive range bins (two 16-byte loads) and the plateau
+// rule is evaluated on bit masks: R / E / F = bin is greater than / equal to / less than its left
+// neighbour.  A run that starts with a rise at s is a peak iff the first bin after s that differs
+// from it is a fall: adding (R << 1) to E lets the carry ripple through the run's equal bins and
+// land on that first differing bin, so  PE = (E + (R << 1)) & ~E & F  marks the falls that close a
+// peak run; 64-bit masks (own bins + the next lane's, fetched with DPP) cover runs that cross one
+// lane boundary, the rare longer run walks the LDS copy of the row.  Candidates, NumPy-ordered
+// sums (8 lanes per <=128-element leaf), threshold and both compactions stay inside the wavefront.
+#define PKW_WAVES 4
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int *total)
+{
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(inc, d);
+        if (lane >= d) inc += n;
+    }
+    *total = __shfl(inc, 63);
+    return inc - v;
+}
+
+__global__ __launch_bounds__(64 * PKW_WAVES) void peaks_rows_u8_wave_kernel(PeakSrc src, int rows, int cols,
+                                                                             uint16_t *__restrict__ row_stage, int stage_cap,
+                                                                             int32_t *__restrict__ row_count)
+{
+    __shared__ __align__(16) uint8_t xb_s[PKW_WAVES][PKF_MAXC + 64];
+    __shared__ __align__(16) uint8_t pc_s[PKW_WAVES][PKF_MAXC / 2];
+    __shared__ __align__(16) uint16_t pm_s[PKW_WAVES][PKF_MAXC / 2];
+    __shared__ float ls_s[PKW_WAVES][16];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y, r = blockIdx.x * PKW_WAVES + wv;
+    if (r >= rows) return;
+    uint8_t *xb = xb_s[wv], *pc = pc_s[wv];
+    uint16_t *pm = pm_s[wv];
+    float *ls = ls_s[wv];
+    const int64_t lane_sel = src.lane_index ? (int64_t)src.lane_index[b] : (int64_t)b;
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
+                       (int64_t)r * src.row_stride + src.payload_off;
+    const int i0 = lane * 32;
+    uint32_t w[8];
+    if (i0 + 31 < cols) {
+        const u32x4_a1 a = *reinterpret_cast<const u32x4_a1 *>(p + i0), c = *reinterpret_cast<const u32x4_a1 *>(p + i0 + 16);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = i0 + 4 * j + q; if (i < cols) v |= (uint32_t)p[i] << (8 * q); }
+            w[j] = v;
+        }
+    }
+    *reinterpret_cast<uint4 *>(xb + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4 *>(xb + i0 + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+    wave_lds_fence();
+    // R / E masks of the own bins (bit k = bin i0 + k against bin i0 + k - 1)
+    uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[7], 0x138, 0xf, 0xf, false) >> 24;      // last bin of lane - 1
+    uint32_t R = 0, E = 0;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const uint32_t cb = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+        R |= (uint32_t)(cb > pb) << k;
+        E |= (uint32_t)(cb == pb) << k;
+        pb = cb;
+    }
+    const int nvalid = min(max(cols - i0, 0), 32);
+    const uint32_t vm = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
+    R &= vm; E &= vm;
+    const uint32_t F = ~(R | E) & vm;
+    if (lane == 0) R &= ~1u;                                   // bin 0 has no left neighbour: never a start
+    const uint32_t En = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)E, 0x130, 0xf, 0xf, false);          // masks of lane + 1 (0 past the row)
+    const uint32_t Fn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)F, 0x130, 0xf, 0xf, false);
+    const unsigned long long E64 = (unsigned long long)E | ((unsigned long long)En << 32);
+    const unsigned long long F64 = (unsigned long long)F | ((unsigned long long)Fn << 32);
+    const unsigned long long Z64 = E64 + ((unsigned long long)R << 1);
+    unsigned long long pe = Z64 & ~E64 & F64;
+    int cnt = __popcll(pe);
+    int extra_mid = -1;
+    uint32_t extra_c = 0;
+    if (Z64 < E64) {                                           // the last run of this lane runs past the next lane too
+        const int sl = 31 - __clz((int)R);
+        extra_c = xb[i0 + sl];
+        int i = i0 + 64;
+        while (i < cols && (uint32_t)xb[i] == extra_c) i++;
+        if (i < cols && (uint32_t)xb[i] < extra_c) { extra_mid = (i0 + sl + i - 1) >> 1; cnt++; }
+    }
+    int M;
+    int pos = wave_excl_scan(cnt, lane, &M);
+    if (M == 0) {
+        if (lane == 0) row_count[b * rows + r] = 0;
+        return;
+    }
+    while (pe) {
+        const int q = __ffsll((long long)pe) - 1;
+        pe &= pe - 1;
+        const uint32_t below = q >= 32 ? R : (R & ((1u << q) - 1u));
+        const int sl = 31 - __clz((int)below);                 // the rise that opened the run closed at q
+        pc[pos] = xb[i0 + sl];
+        pm[pos] = (uint16_t)(i0 + ((sl + q - 1) >> 1));
+        pos++;
+    }
+    if (extra_mid >= 0) { pc[pos] = (uint8_t)extra_c; pm[pos] = (uint16_t)extra_mid; }
+    wave_lds_fence();
+
+    // NumPy pairwise sums: 8 lanes per leaf (one per accumulator), up to 16 leaves in two passes
+    int nleaf = 0, lo1 = 0, n1 = -1, lo2 = 0, n2 = -1;
+    PwWalk<4>::select(0, M, lane >> 3, nleaf, lo1, n1);
+    if (nleaf > 8) { int c2 = 0; PwWalk<4>::select(0, M, 8 + (lane >> 3), c2, lo2, n2); }
+    const int j8 = lane & 7;
+    auto leaf = [&](int lo, int n, auto val) -> float {
+        float res = 0.f;
+        if (n >= 8) {
+            float rj = val(lo + j8);
+            const int nn = n - (n & 7);
+            for (int i = 8; i < nn; i += 8) rj = __fadd_rn(rj, val(lo + i + j8));
+            rj = __fadd_rn(rj, __shfl_xor(rj, 1));
+            rj = __fadd_rn(rj, __shfl_xor(rj, 2));
+            rj = __fadd_rn(rj, __shfl_xor(rj, 4));
+            res = rj;
+            if (j8 == 0) for (int i = nn; i < n; i++) res = __fadd_rn(res, val(lo + i));
+        } else if (n >= 0) {
+            if (j8 == 0) for (int i = 0; i < n; i++) res = __fadd_rn(res, val(lo + i));    // short leaf (M < 8)
+        }
+        return res;
+    };
+    auto np_sum = [&](auto val) -> float {
+        const float r1 = leaf(lo1, n1, val);
+        if (n1 >= 0 && j8 == 0) ls[lane >> 3] = r1;
+        if (nleaf > 8) {
+            const float r2 = leaf(lo2, n2, val);
+            if (n2 >= 0 && j8 == 0) ls[8 + (lane >> 3)] = r2;
+        }
+        wave_lds_fence();
+        int li = 0;
+        const float tot = PwWalk<4>::combine(ls, M, li);
+        wave_lds_fence();
+        return tot;
+    };
+    const float fM = (float)M;
+    const float mean = __fdiv_rn(np_sum([&](int k) { return code_to_f32_pk(pc[k]); }), fM);
+    const float var = __fdiv_rn(np_sum([&](int k) { const float d = __fsub_rn(code_to_f32_pk(pc[k]), mean); return __fmul_rn(d, d); }), fM);
+    const float thr = __fadd_rn(mean, rn_sqrtf(var));
+    // threshold + ordered compaction: 16 consecutive candidates per lane (M <= 1024)
+    const int k0 = lane * 16;
+    const uint4 cw = *reinterpret_cast<const uint4 *>(pc + k0);
+    const uint32_t cws[4] = {cw.x, cw.y, cw.z, cw.w};
+    uint32_t keep = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t c = (cws[q >> 2] >> (8 * (q & 3))) & 255u;
+        keep |= (uint32_t)((k0 + q < M) && (code_to_f32_pk(c) >= thr)) << q;
+    }
+    int total;
+    int p2 = wave_excl_scan(__popc(keep), lane, &total);
+    uint16_t *dst = row_stage + ((int64_t)b * rows + r) * stage_cap;
+    while (keep) {
+        const int q = __ffs((int)keep) - 1;
+        keep &= keep - 1;
+        if (p2 < stage_cap) dst[p2] = pm[k0 + q];
+        p2++;
+    }
+    if (lane == 0) row_count[b * rows + r] = total;
 }
 
 // per lane: exclusive scan of row counts, then emit (az, rng) pairs azimuth-major
@@ -368,7 +533,8 @@ hipError_t launch_peaks(hipStream_t st, PeakSrc src, int B, int rows, int cols, 
     size_t lds = sizeof(float) * (size_t)(cols + cols / 8 + 2 + 2 * half) + sizeof(uint16_t) * (size_t)half + 16;
     dim3 grid(rows, B), block(PK_T);
     if (src.is_u8 && cols <= PKF_MAXC && cols >= 3)
-        hipLaunchKernelGGL(peaks_rows_u8_kernel, grid, block, 0, st, src, rows, cols, row_stage, stage_cap, row_count);
+        hipLaunchKernelGGL(peaks_rows_u8_wave_kernel, dim3((rows + PKW_WAVES - 1) / PKW_WAVES, B), dim3(64 * PKW_WAVES), 0, st, src, rows,
+                           cols, row_stage, stage_cap, row_count);
     else if (src.is_u8)
         hipLaunchKernelGGL(peaks_rows_kernel<true>, grid, block, lds, st, src, rows, cols, row_stage, stage_cap, row_count);
     else
