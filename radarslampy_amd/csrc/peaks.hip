@@ -3,7 +3,9 @@
 // Replaces getPointCloud.getPointCloudPolarInd (reference getPointCloud.py:11-54) fused with
 // the u8 -> float32 decode of parseData.extractDataFromRadarImage (parseData.py:40,49-51).
 //
-// One 256-thread workgroup per azimuth row (grid = rows x lanes): the row is staged once
+// Live configuration (u8 record rows, <= 2048 range bins): ONE WAVEFRONT per azimuth row, see
+// peaks_rows_u8_wave_kernel below.  Generic path (f32 rows or longer rows):
+// one 256-thread workgroup per azimuth row (grid = rows x lanes): the row is staged once
 // through LDS (coalesced HBM read of the u8 payload / f32 row), every range bin is tested
 // for "left edge of a strict local maximum" (SciPy plateau rule: run of equal samples with
 // a strict rise before and a strict fall after, midpoint (l+r)/2, end samples never peaks),
@@ -201,126 +203,11 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
 }
 
 // ---- specialised row kernel for the live configuration: u8 record rows, cols <= 2048 -----------
-// One thread per 8 consecutive range bins, the 8 power codes stay in registers (the u8 -> float32
-// map k -> k/255 is strictly increasing, so maxima / plateaus are found on the integer codes and
-// only the surviving candidates are converted), neighbours come from an LDS byte copy of the row,
-// NumPy-order leaf sums use 8 lanes per leaf (one per accumulator, combined by a 3-step butterfly
-// that reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) exactly), at most 4 candidates per thread.
+// The u8 -> float32 map k -> k/255 is strictly increasing, so maxima / plateaus are found on the
+// integer codes and only the surviving candidates are converted.
 #define PKF_MAXC 2048
-typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
-__global__ __launch_bounds__(PK_T) void peaks_rows_u8_kernel(PeakSrc src, int rows, int cols,
-                                                             uint16_t *__restrict__ row_stage, int stage_cap,
-                                                             int32_t *__restrict__ row_count)
-{
-    __shared__ __align__(16) uint8_t xb[PKF_MAXC + 16];
-    __shared__ float ph[PKF_MAXC / 2], sq[PKF_MAXC / 2];
-    __shared__ uint16_t pm[PKF_MAXC / 2];
-    __shared__ float leaf_sum[PK_T / 8];
-    __shared__ int scan_sh[8];
-    const int b = blockIdx.y, r = blockIdx.x, t = threadIdx.x;
-    const int64_t lane_sel = src.lane_index ? (int64_t)src.lane_index[b] : (int64_t)b;
-    const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
-                       (int64_t)r * src.row_stride + src.payload_off;
-    const int base = t * 8;
-    uint32_t v[8];
-    if (base + 7 < cols) {
-        // one 8-byte load per thread: record rows are not dword aligned (stride 3779, payload at +11);
-        // the hardware handles the misaligned access, eight byte loads cost eight trips through the TA
-        const u32x2_a1 wv = *reinterpret_cast<const u32x2_a1 *>(p + base);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = (wv.x >> (8 * j)) & 255u; v[4 + j] = (wv.y >> (8 * j)) & 255u; }
-        *reinterpret_cast<uint2 *>(&xb[base]) = make_uint2(wv.x, wv.y);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (base + j < cols) ? (uint32_t)p[base + j] : 0u;
-        const uint32_t w0 = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-        const uint32_t w1 = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
-        *reinterpret_cast<uint2 *>(&xb[base]) = make_uint2(w0, w1);
-    }
-    __syncthreads();
-    const int imax = cols - 1;
-    const uint32_t prev = (base > 0) ? (uint32_t)xb[base - 1] : 0u;
-
-    // candidate test for element j of this thread's chunk; returns the plateau midpoint or -1
-    auto peak_mid = [&](int j) -> int {
-        const int i = base + j;
-        if (i < 1 || i >= imax) return -1;
-        const uint32_t c = v[j];
-        const uint32_t left = (j > 0) ? v[j > 0 ? j - 1 : 0] : prev;
-        if (!(left < c)) return -1;
-        const uint32_t nxt = (j < 7) ? v[j < 7 ? j + 1 : 7] : (uint32_t)xb[i + 1];
-        if (nxt < c) return i;
-        if (nxt > c) return -1;
-        int ia = i + 1;                               // plateau: walk the LDS copy
-        while (ia < imax && (uint32_t)xb[ia] == c) ia++;
-        return ((uint32_t)xb[ia] < c) ? ((i + ia - 1) >> 1) : -1;
-    };
-    int mids[8];
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) { mids[j] = peak_mid(j); cnt += mids[j] >= 0; }
-    int M;
-    int pos = block_excl_scan(cnt, scan_sh, &M);
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        if (mids[j] >= 0) { ph[pos] = code_to_f32_pk(v[j]); pm[pos] = (uint16_t)mids[j]; pos++; }
-    __syncthreads();
-    if (M == 0) {
-        if (t == 0) row_count[b * rows + r] = 0;
-        return;
-    }
-    // NumPy pairwise sum with 8 lanes per leaf.  The leaf decomposition depends only on M: it is walked once
-    // per thread and reused for both sums; the tree is combined by one thread and published through LDS
-    // (the kernel is instruction-bound: PMC showed more SALU than VALU instructions, most of them in the
-    // four redundant recursion walks per wavefront of the previous version).
-    int lcnt = 0, my_lo = 0, my_n = -1;
-    PwWalk<4>::select(0, M, t >> 3, lcnt, my_lo, my_n);
-    auto np_sum = [&](const float *a) -> float {
-        const int j = t & 7;
-        float res = 0.f;
-        if (my_n >= 8) {
-            float rj = a[my_lo + j];
-            const int nn = my_n - (my_n & 7);
-            for (int i = 8; i < nn; i += 8) rj = __fadd_rn(rj, a[my_lo + i + j]);
-            rj = __fadd_rn(rj, __shfl_xor(rj, 1));
-            rj = __fadd_rn(rj, __shfl_xor(rj, 2));
-            rj = __fadd_rn(rj, __shfl_xor(rj, 4));
-            res = rj;
-            if (j == 0) for (int i = nn; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);
-        } else if (my_n >= 0) {
-            if (j == 0) for (int i = 0; i < my_n; i++) res = __fadd_rn(res, a[my_lo + i]);   // short leaf (M < 8)
-        }
-        if (my_n >= 0 && j == 0) leaf_sum[t >> 3] = res;
-        __syncthreads();
-        if (t == 0) { int li = 0; leaf_sum[PK_T / 8 - 1] = PwWalk<4>::combine(leaf_sum, M, li); }
-        __syncthreads();
-        return leaf_sum[PK_T / 8 - 1];
-    };
-    const float fM = (float)M;
-    const float mean = __fdiv_rn(np_sum(ph), fM);
-    for (int k = t; k < M; k += PK_T) {
-        float d = __fsub_rn(ph[k], mean);
-        sq[k] = __fmul_rn(d, d);
-    }
-    __syncthreads();
-    const float var = __fdiv_rn(np_sum(sq), fM);
-    const float thr = __fadd_rn(mean, rn_sqrtf(var));
-    // threshold + ordered compaction: 4 consecutive candidates per thread (M <= 1024)
-    int c2 = 0;
-    bool keep[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { const int k = t * 4 + q; keep[q] = (k < M) && (ph[k] >= thr); c2 += keep[q]; }
-    int total;
-    int p2 = block_excl_scan(c2, scan_sh, &total);
-    uint16_t *dst = row_stage + ((int64_t)b * rows + r) * stage_cap;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (keep[q]) { if (p2 < stage_cap) dst[p2] = pm[t * 4 + q]; p2++; }
-    if (t == 0) row_count[b * rows + r] = total;
-}
-
-// ---- one wavefront per azimuth row (u8 records, cols <= 2048): no workgroup barrier anywhere.
-// The 256-thread version above spends its time in instruction issue (PMC: more SALU than VALU
+// one wavefront per azimuth row: no workgroup barrier anywhere.
+// The first version (256 threads per row, 8 bins per thread) spent its time in instruction issue (PMC: more SALU than VALU
 // instructions - eight divergent plateau tests per thread, two block scans, a dozen barriers for
 // 2 KB of data).  Here a lane owns 32 consecutive range bins (two 16-byte loads) and the plateau
 // rule is evaluated on bit masks: R / E / F = bin is greater than / equal to / less than its left

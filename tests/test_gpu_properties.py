@@ -126,3 +126,32 @@ def test_peaks_u8_ragged_clips(ctx):
         got = ctx.peaks_record_u8(rec, payload_off=off, clip=clip)
         want = oracle.peaks_from_record_u8(rec, off, clip)
         assert np.array_equal(got, want), (rows, clip, off)
+
+
+def test_peaks_u8_long_plateaus(ctx):
+    """flat-topped peaks of every length 1..200 at offsets that straddle the 32-bin lane and 64-bin
+    lookahead boundaries of the wave-per-row kernel, plateaus touching both ends of the row, staircases"""
+    rng = np.random.default_rng(23)
+    off, clip, stride = 11, 2025, 3779
+    rows = []
+    for length in list(range(1, 70)) + [95, 96, 97, 127, 128, 129, 200, 500, 1500, 2023]:
+        for start in (1, 2, 31, 32, 33, 63, 64, 65, 700, clip - length - 1, clip - length):
+            if start < 0 or start + length > clip:
+                continue
+            row = np.full(clip, 10, np.uint8)
+            row[start:start + length] = 200                       # plateau (a peak iff it does not touch either end)
+            rows.append(row)
+    stair = np.repeat(np.arange(1, 64, dtype=np.uint8), 33)[:clip]             # rising staircase then a drop
+    stair = np.concatenate([stair, np.zeros(clip - stair.size, np.uint8)])
+    rows.append(stair)
+    rows.append(stair[::-1].copy())
+    rows.append(np.zeros(clip, np.uint8))
+    noisy = rng.integers(0, 3, size=(40, clip), dtype=np.uint8) * 100                         # long equal runs of 3 levels
+    rows.extend(list(noisy))
+    rec = np.zeros((len(rows), stride), np.uint8)
+    rec[:, off:off + clip] = np.stack(rows)
+    rec[:, off + clip:] = 255                                                                # bytes after the payload must be ignored
+    got = ctx.peaks_record_u8(rec, payload_off=off, clip=clip)
+    want = oracle.peaks_from_record_u8(rec, off, clip)
+    assert want.shape[0] > 300
+    assert np.array_equal(got, want)
