@@ -115,7 +115,7 @@ def test_pyr_down(ctx, cart_pair):
         assert np.array_equal(got, want), img.shape
         img = want
     rng = np.random.default_rng(6)
-    for h, w in [(16, 16), (17, 31), (65, 130), (129, 64)]:
+    for h, w in [(16, 16), (17, 31), (65, 130), (129, 64), (20, 18), (33, 22), (9, 2046), (12, 2048), (70, 1030), (5, 20), (4, 16)]:
         im = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
         assert np.array_equal(ctx.pyr_down_u8(im), oracle.build_pyramid(im, 1)[1]), (h, w)
 
