@@ -217,7 +217,9 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
 // peak run; 64-bit masks (own bins + the next lane's, fetched with DPP) cover runs that cross one
 // lane boundary, the rare longer run walks the LDS copy of the row.  Candidates, NumPy-ordered
 // sums (8 lanes per <=128-element leaf), threshold and both compactions stay inside the wavefront.
-#define PKW_WAVES 4
+#ifndef PKW_WAVES
+#define PKW_WAVES 2          // rows (wavefronts) per workgroup: small workgroups (10 KB LDS) slot in next to the warp's
+#endif
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 
 __device__ __forceinline__ void wave_lds_fence()

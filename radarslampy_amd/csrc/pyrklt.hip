@@ -238,15 +238,55 @@ hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, 
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+// exact 64-bit wavefront sum, returned to every lane.  Every KLT iteration ends in two of these, so
+// their latency is the iteration's critical path: four DPP steps (quad xor 1, quad xor 2, half-row
+// mirror, row mirror - ~10 cycles each against ~100 for a ds_bpermute shuffle) leave the 16-lane row
+// sums in every lane, the four row sums are read as scalars.  Integer addition: the order is free.
+template <int CTRL> __device__ __forceinline__ long long dpp_move_ll(long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__device__ __forceinline__ long long readlane_ll(long long v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
+    v += dpp_move_ll<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_move_ll<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_move_ll<0x141>(v);      // row_half_mirror
+    v += dpp_move_ll<0x140>(v);      // row_mirror
+    return (readlane_ll(v, 0) + readlane_ll(v, 16)) + (readlane_ll(v, 32) + readlane_ll(v, 48));
+}
+
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+
+// 32 x 32 neighbourhood of the next image with origin (tx0, ty0): 4 bytes per lane and pass, one dword LDS
+// write; interior tiles use misaligned dword loads, border tiles the REFLECT_101 byte gather
+__device__ __forceinline__ void load_j_tile(const uint8_t *__restrict__ J, int w, int h, int tx0, int ty0, int lane,
+                                            uint8_t (*Jt8)[36])
+{
+    if (tx0 >= 0 && tx0 + 32 <= w && ty0 >= 0 && ty0 + 32 <= h) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        int lo = __shfl_xor((int)(v & 0xffffffffll), m);
-        int hi = __shfl_xor((int)(v >> 32), m);
-        v += ((long long)hi << 32) | (unsigned int)lo;
+        for (int i = lane; i < 32 * 8; i += 64) {
+            const int y = i >> 3, c4 = (i & 7) * 4;
+            *reinterpret_cast<uint32_t *>(&Jt8[y][c4]) = *reinterpret_cast<const u32_a1 *>(J + (int64_t)(ty0 + y) * w + (tx0 + c4));
+        }
+    } else {
+        for (int i = lane; i < 32 * 8; i += 64) {
+            const int y = i >> 3, c4 = (i & 7) * 4;
+            const uint8_t *jr = J + (int64_t)reflect101(ty0 + y, h) * w;
+            const uint32_t pk = (uint32_t)jr[reflect101(tx0 + c4, w)] | ((uint32_t)jr[reflect101(tx0 + c4 + 1, w)] << 8) |
+                                ((uint32_t)jr[reflect101(tx0 + c4 + 2, w)] << 16) | ((uint32_t)jr[reflect101(tx0 + c4 + 3, w)] << 24);
+            *reinterpret_cast<uint32_t *>(&Jt8[y][c4]) = pk;
+        }
     }
-    return v;
 }
 
 __device__ __forceinline__ void bilin_weights(float a, float b, int &iw00, int &iw01, int &iw10, int &iw11)
@@ -316,9 +356,18 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
         bilin_weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy), iw00, iw01, iw10, iw11);
 
         __syncthreads();
-        for (int i = lane; i < 18 * 18; i += 64) {
-            int ty = i / 18, tx = i - ty * 18;
-            It8[ty][tx] = I[(int64_t)reflect101(ipy - 1 + ty, h) * w + reflect101(ipx - 1 + tx, w)];
+        if (ipx >= 1 && ipx + 19 <= w && ipy >= 1 && ipy + 17 <= h) {
+            // interior window: 18 rows x 5 dwords (the rows of the tile are 20 bytes), misaligned dword loads
+            for (int i = lane; i < 18 * 5; i += 64) {
+                const int ty = i / 5, q = i - ty * 5;
+                reinterpret_cast<uint32_t *>(&It8[ty][0])[q] =
+                    *reinterpret_cast<const u32_a1 *>(I + (int64_t)(ipy - 1 + ty) * w + (ipx - 1 + 4 * q));
+            }
+        } else {
+            for (int i = lane; i < 18 * 18; i += 64) {
+                int ty = i / 18, tx = i - ty * 18;
+                It8[ty][tx] = I[(int64_t)reflect101(ipy - 1 + ty, h) * w + reflect101(ipx - 1 + tx, w)];
+            }
         }
         __syncthreads();
         {   // Scharr derivatives of a 16x16 block: lane -> row y, columns xg..xg+3, three rows of 6 bytes each
@@ -415,13 +464,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
             if (!(inx >= tx0 && inx - tx0 <= 15 && iny >= ty0 && iny - ty0 <= 15)) {
                 tx0 = inx - 8; ty0 = iny - 8;
                 __syncthreads();
-                for (int i = lane; i < 32 * 8; i += 64) {            // 4 bytes per lane, one dword LDS write
-                    const int y = i >> 3, c4 = (i & 7) * 4;
-                    const uint8_t *jr = J + (int64_t)reflect101(ty0 + y, h) * w;
-                    const uint32_t pk = (uint32_t)jr[reflect101(tx0 + c4, w)] | ((uint32_t)jr[reflect101(tx0 + c4 + 1, w)] << 8) |
-                                        ((uint32_t)jr[reflect101(tx0 + c4 + 2, w)] << 16) | ((uint32_t)jr[reflect101(tx0 + c4 + 3, w)] << 24);
-                    *reinterpret_cast<uint32_t *>(&Jt8[y][c4]) = pk;
-                }
+                load_j_tile(J, w, h, tx0, ty0, lane, Jt8);
                 __syncthreads();
             }
             const int jox = inx - tx0, joy = iny - ty0;
@@ -462,13 +505,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
             if (!(iex >= tx0 && iex - tx0 <= 15 && iey >= ty0 && iey - ty0 <= 15)) {
                 tx0 = iex - 8; ty0 = iey - 8;
                 __syncthreads();
-                for (int i = lane; i < 32 * 8; i += 64) {            // 4 bytes per lane, one dword LDS write
-                    const int y = i >> 3, c4 = (i & 7) * 4;
-                    const uint8_t *jr = J + (int64_t)reflect101(ty0 + y, h) * w;
-                    const uint32_t pk = (uint32_t)jr[reflect101(tx0 + c4, w)] | ((uint32_t)jr[reflect101(tx0 + c4 + 1, w)] << 8) |
-                                        ((uint32_t)jr[reflect101(tx0 + c4 + 2, w)] << 16) | ((uint32_t)jr[reflect101(tx0 + c4 + 3, w)] << 24);
-                    *reinterpret_cast<uint32_t *>(&Jt8[y][c4]) = pk;
-                }
+                load_j_tile(J, w, h, tx0, ty0, lane, Jt8);
                 __syncthreads();
             }
             const int eox = iex - tx0, eoy = iey - ty0;
