@@ -19,16 +19,33 @@
 #define LM_TMAX 256
 #define TWO_PI 6.283185307179586476925286766559
 
+// wavefront sum returned to every lane.  The solve is a chain of short dependent reductions, so the
+// latency of one reduction matters: four DPP steps (quad xor 1, quad xor 2, half-row mirror, row
+// mirror: ~10 cycles each, against ~100 for a ds_bpermute shuffle) leave the 16-lane row sums in
+// every lane of the row, the four row sums are then read as scalars and added in a fixed order.
+template <int CTRL> __device__ __forceinline__ double dpp_move_d(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        long long bits = __double_as_longlong(v);
-        int lo = __shfl_xor((int)(bits & 0xffffffffll), m);
-        int hi = __shfl_xor((int)(bits >> 32), m);
-        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    }
-    return v;
+    v += dpp_move_d<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_move_d<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_move_d<0x141>(v);       // row_half_mirror
+    v += dpp_move_d<0x140>(v);       // row_mirror
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 // block-wide sum, result returned to every thread (deterministic order)
