@@ -117,13 +117,24 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
     }
 }
 
+__device__ __forceinline__ uint32_t pyr_hpair(uint32_t d0, uint32_t d1, uint32_t d2)
+{
+    // bytes b0..b3 = d0, b4..b7 = d1, b8.. = d2; left output = b2+4b3+6b4+4b5+b6, right = b4+4b5+6b6+4b7+b8
+    const uint32_t mid = __builtin_amdgcn_alignbyte(d1, d0, 2);                           // b2 b3 b4 b5
+    const uint32_t lo = __builtin_amdgcn_udot4(d1, 0x00010000u, __builtin_amdgcn_udot4(mid, 0x04060401u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(d2, 0x00000001u, __builtin_amdgcn_udot4(d1, 0x04060401u, 0u, false), false);
+    return lo | (hi << 16);
+}
+
 // ---- streaming variant for dword-aligned images up to 2048 wide (pyramid levels 0->1, 1->2)
 // One block owns PR_CH output rows over the FULL image width and streams the 2*PR_CH+3 input rows
 // through LDS: every input row is read once, as one contiguous w-byte burst (DRAM-page friendly:
 // the tiled variant above touches 136-byte segments and measured 0.87 TB/s), 4 rows of loads are
 // kept in flight in registers ahead of the row being filtered, the horizontally filtered rows
 // live in a 5-deep LDS ring (u16 pairs), and one output row is emitted every second input row.
+#ifndef PR_CH
 #define PR_CH 32
+#endif
 #define PR_MAXW 2048
 #define PR_AHEAD 4
 __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__restrict__ src, int64_t src_lane_stride,
@@ -195,6 +206,104 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
     }
 }
 
+// ---- two levels in one pass (1012 -> 506 -> 253): the 506-wide level is neither dword aligned nor large
+// enough to stream well on its own (the tiled kernel above reaches 0.8 TB/s on it).  A block produces PF_CC
+// rows of the SECOND output level: it streams the input rows exactly like pyr_down_rows_kernel to make the
+// 2 * PF_CC + 3 rows of the first output level those need (the 3 halo rows are recomputed by the neighbouring
+// block: 9 % more input reads, no re-read of the intermediate level), keeps them in LDS with their
+// REFLECT_101 pads, writes the ones it owns, and filters the kept rows once more.
+#ifndef PF_CC
+#define PF_CC 12
+#endif
+#define PF_NB (2 * PF_CC + 3)
+#define PF_PITCH 528              // 4 pad bytes + up to 512 pixels + 2 pad bytes, multiple of 16
+#define PF_MAXW 1024
+__global__ __launch_bounds__(256) void pyr_down2_rows_kernel(const uint8_t *__restrict__ src, int64_t src_lane_stride,
+                                                             int w, int h, uint8_t *__restrict__ dst,
+                                                             int64_t dst_lane_stride, int dw, int dh,
+                                                             uint8_t *__restrict__ dst2, int64_t dst2_lane_stride,
+                                                             int dw2, int dh2)
+{
+    __shared__ __align__(16) uint32_t rowbuf[PF_MAXW / 4 + 2];
+    __shared__ __align__(16) uint32_t hb[5][PF_MAXW / 4];
+    __shared__ __align__(16) uint8_t brow[PF_NB][PF_PITCH];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int c0 = blockIdx.x * PF_CC;
+    const int nc = min(PF_CC, dh2 - c0);
+    const int lo = max(2 * c0 - 2, 0), hi = min(2 * (c0 + nc - 1) + 2, dh - 1);      // first-level rows kept
+    const int nout = hi - lo + 1;
+    const int own0 = 2 * c0, own1 = min(2 * (c0 + nc), dh);                           // first-level rows written
+    const int oy0 = lo;
+    const int nin = 2 * nout + 3;
+    const uint8_t *s = src + (int64_t)b * src_lane_stride;
+    uint8_t *d = dst + (int64_t)b * dst_lane_stride;
+    const int wq = w >> 2;                       // dwords per input row (<= 256)
+    const int npair = dw >> 1;                   // output pairs per row (dw even)
+    uint32_t pre[PR_AHEAD];
+    auto load_row = [&](int i, uint32_t &r) {
+        const int sy = reflect101(2 * oy0 - 2 + i, h);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(s + (int64_t)sy * w);
+        r = (t < wq) ? rp[t] : 0u;
+    };
+#pragma unroll
+    for (int k = 0; k < PR_AHEAD; k++) if (k < nin) load_row(k, pre[k]);
+    for (int i0 = 0; i0 < nin; i0 += PR_AHEAD) {
+#pragma unroll
+        for (int k = 0; k < PR_AHEAD; k++) {
+            const int i = i0 + k;
+            if (i < nin) {
+                if (t < wq) rowbuf[1 + t] = pre[k];
+                if (t == 0) rowbuf[0] = (((pre[k] >> 16) & 255) << 16) | (((pre[k] >> 8) & 255) << 24);
+                if (t == wq - 1) rowbuf[1 + wq] = ((pre[k] >> 16) & 255) | (((pre[k] >> 8) & 255) << 8);
+                if (i + PR_AHEAD < nin) load_row(i + PR_AHEAD, pre[k]);
+                __syncthreads();
+                uint32_t *hrow = hb[i % 5];
+                if (t < npair) hrow[t] = pyr_hpair(rowbuf[t], rowbuf[t + 1], rowbuf[t + 2]);
+                __syncthreads();
+                if (i >= 4 && !(i & 1)) {
+                    const int ko = (i - 4) >> 1, row = oy0 + ko;
+                    const uint32_t *r0 = hb[(i - 4) % 5], *r1 = hb[(i - 3) % 5], *r2 = hb[(i - 2) % 5], *r3 = hb[(i - 1) % 5], *r4 = hb[i % 5];
+                    if (t < npair) {
+                        const uint32_t sum = (r0[t] + r4[t]) + 4u * (r1[t] + r3[t]) + 6u * r2[t] + 0x00800080u;
+                        const uint16_t o2 = (uint16_t)__builtin_amdgcn_perm(0u, sum, 0x0c0c0301u);
+                        *reinterpret_cast<uint16_t *>(&brow[ko][4 + 2 * t]) = o2;
+                        if (row >= own0 && row < own1) reinterpret_cast<uint16_t *>(d + (int64_t)row * dw)[t] = o2;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = t; r < nout; r += 256) {                      // REFLECT_101 pads of the kept rows
+        brow[r][2] = brow[r][4 + 2]; brow[r][3] = brow[r][4 + 1];
+        brow[r][4 + dw] = brow[r][4 + dw - 2]; brow[r][4 + dw + 1] = brow[r][4 + dw - 3];
+    }
+    __syncthreads();
+    // second level: two rows at a time (128 threads each), one output pair per thread
+    uint8_t *d2 = dst2 + (int64_t)b * dst2_lane_stride;
+    const int npair2 = (dw2 + 1) >> 1;
+    const int half = t >> 7, tq = t & 127;
+    for (int q0 = 0; q0 < npair2; q0 += 128) {
+        const int q = q0 + tq;
+        for (int ci = half; ci < nc; ci += 2) {
+            const int c = c0 + ci;
+            if (q < npair2) {
+                uint32_t hv[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const uint32_t *rw = reinterpret_cast<const uint32_t *>(&brow[reflect101(2 * c - 2 + j, dh) - lo][0]);
+                    hv[j] = pyr_hpair(rw[q], rw[q + 1], rw[q + 2]);
+                }
+                const uint32_t sum = (hv[0] + hv[4]) + 4u * (hv[1] + hv[3]) + 6u * hv[2] + 0x00800080u;
+                const uint32_t o2 = __builtin_amdgcn_perm(0u, sum, 0x0c0c0301u);
+                uint8_t *orow = d2 + (int64_t)c * dw2;
+                orow[2 * q] = (uint8_t)o2;
+                if (2 * q + 1 < dw2) orow[2 * q + 1] = (uint8_t)(o2 >> 8);
+            }
+        }
+    }
+}
+
 hipError_t launch_pyr_down(hipStream_t st, const uint8_t *src, int64_t src_lane_stride, int w, int h,
                            uint8_t *dst, int64_t dst_lane_stride, int B)
 {
@@ -226,8 +335,20 @@ void pyr_desc_init(PyrDesc *d, int w, int h)
 hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, int B)
 {
     for (int l = 0; l + 1 < ROAM_PYR_LEVELS; l++) {
-        hipError_t e = launch_pyr_down(st, pyr + d.off[l], d.lane_stride, d.w[l], d.h[l],
-                                       pyr + d.off[l + 1], d.lane_stride, B);
+        const int w = d.w[l], h = d.h[l], dw = d.w[l + 1], dh = d.h[l + 1];
+        // the last two levels in one pass when the shapes allow it (1012 -> 506 -> 253)
+        if (l + 2 < ROAM_PYR_LEVELS && (w & 3) == 0 && w >= 64 && w <= PF_MAXW && (dw & 1) == 0 && h >= 16 && dh >= 8 &&
+            (d.lane_stride & 3) == 0 && (d.off[l] & 3) == 0 && (d.off[l + 1] & 1) == 0 && (reinterpret_cast<uintptr_t>(pyr) & 3) == 0) {
+            const int dw2 = d.w[l + 2], dh2 = d.h[l + 2];
+            dim3 grid((dh2 + PF_CC - 1) / PF_CC, B);
+            hipLaunchKernelGGL(pyr_down2_rows_kernel, grid, dim3(256), 0, st, pyr + d.off[l], d.lane_stride, w, h,
+                               pyr + d.off[l + 1], d.lane_stride, dw, dh, pyr + d.off[l + 2], d.lane_stride, dw2, dh2);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            l++;
+            continue;
+        }
+        hipError_t e = launch_pyr_down(st, pyr + d.off[l], d.lane_stride, w, h, pyr + d.off[l + 1], d.lane_stride, B);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
