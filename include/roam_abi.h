@@ -200,6 +200,20 @@ int32_t roam_engine_doh_maxima(roam_ctx *ctx, int32_t pool_idx, const double *si
 int32_t roam_engine_lane_image(roam_ctx *ctx, int32_t lane, int32_t level, uint8_t *out, int64_t cap);
 /* replace a lane's feature set (retrack append, getFeatures.appendNewFeatures getFeatures.py:98-118) */
 int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, int32_t K);
+
+/* ---- device-resident keyframe map (reference Mapping.Map.keyframes / addKeyframe,
+ * Mapping.py:118-147; keyframes are created at RawROAMSystem.py:186-190 and :250-270).
+ * Every keyframe of a lane stays in HBM.  The LIVE keyframe is the one the tracker prunes each frame
+ * (Keyframe.pruneFeaturePoints, Mapping.py:118-125); when it is replaced - inside roam_engine_step when
+ * the pose moved >= 0.2 rad / 2 m or the features ran out, or by roam_engine_set_features - its final
+ * state {pose, velocity at creation, undistorted pruned locals, pool scan it was created on} is copied
+ * device-to-device into the lane's ring.  Index 0 is the oldest keyframe, count-1 the live one.
+ * A full ring drops further keyframes (count stays at keyframes_per_lane + 1). */
+int32_t roam_engine_map_reserve(roam_ctx *ctx, int32_t keyframes_per_lane);
+int32_t roam_engine_map_count(roam_ctx *ctx, int32_t lane, int32_t *count);
+/* blocking read-back of one keyframe: locals_xy receives n (x, y) pairs in metres (prunedUndistortedLocals) */
+int32_t roam_engine_map_get(roam_ctx *ctx, int32_t lane, int32_t index, double *pose3, double *vel3, double *locals_xy,
+                            int32_t cap_pts, int32_t *n_out, int32_t *scan_out);
 /* per-stage device time of the last step in milliseconds (hipEvent pairs on the stream);
  * names_out receives n pointers to static strings. */
 int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap,

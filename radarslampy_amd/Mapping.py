@@ -55,3 +55,33 @@ class Map():
 
     def addKeyframe(self, keyframe: Keyframe) -> None:
         self.keyframes.append(keyframe)
+
+
+class DeviceMap():
+    """the keyframes of one engine lane, resident in HBM (roam_engine_map_*).  Read-only view with the
+    reference's attribute names; `keyframes[-1]` is the live keyframe the tracker is pruning."""
+
+    class _KF():
+        def __init__(self, d):
+            self.pose, self.velocity = d["pose"], d["velocity"]
+            self.prunedUndistortedLocals = d["prunedUndistortedLocals"]
+            self.scan = d["scan"]
+
+        def getPrunedFeaturesGlobalPosition(self) -> np.ndarray:
+            return _se2_apply(self.pose, self.prunedUndistortedLocals)
+
+    def __init__(self, engine, lane: int) -> None:
+        self.engine, self.lane = engine, int(lane)
+
+    def __len__(self) -> int:
+        return self.engine.map_count(self.lane)
+
+    @property
+    def keyframes(self):
+        return [DeviceMap._KF(d) for d in self.engine.map_keyframes(self.lane)]
+
+    def isGoodKeyframe(self, pose) -> bool:
+        """rotation >= 0.2 rad or squared translation >= 4 m^2 w.r.t. the live keyframe (Mapping.py:149-174)"""
+        last = self.engine.map_keyframe(self.lane, len(self) - 1)["pose"]
+        pose = np.asarray(pose)
+        return bool(abs(last[2] - pose[2]) >= ROT_THRESHOLD or np.sum((last[:2] - pose[:2]) ** 2) >= TRANS_THRESHOLD_SQ)

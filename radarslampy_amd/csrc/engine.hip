@@ -51,6 +51,14 @@ struct Engine {
     double *kab_src = nullptr, *kab_tgt = nullptr, *kab_out = nullptr;
     int32_t *in_n = nullptr;
     double *kf_pose = nullptr, *kf_und = nullptr, *kf_und_tmp = nullptr;   // B x 3, B x KS x 2
+    // f1: device-resident keyframe map (Mapping.Map.keyframes): the live keyframe's creation velocity / scan,
+    // and a per-lane ring of frozen keyframes {pose, velocity, n, scan | n x 2 undistorted locals}
+    double *kf_vel = nullptr;                                              // B x 3
+    int32_t *kf_scan = nullptr, *kf_fresh = nullptr, *kf_live = nullptr;   // B
+    double *map_store = nullptr;                                           // B x map_cap x MAP_SLOT
+    int32_t *map_n = nullptr;                                              // B
+    int map_cap = 0;
+    std::vector<int32_t> last_scan;                                        // host: scan of each lane's latest step
     double *pose = nullptr, *vel = nullptr;                                // B x 3
     double *T_wj0 = nullptr, *T_init = nullptr, *p_w = nullptr, *p_jt = nullptr;
     double *lm_work = nullptr, *lm_out = nullptr;
@@ -214,6 +222,39 @@ __global__ void g3_init_transform_kernel(const double *__restrict__ kab_out, con
     Ti[6] = 0; Ti[7] = 0; Ti[8] = 1;
 }
 
+// f1 keyframe map: one slot = 8-double header {pose[3], velocity[3], n, scan} + KS x 2 undistorted locals
+#define MAP_SLOT (8 + 2 * KS)
+// copy a keyframe that is about to be replaced into the lane's ring (whole block; returns through *ok)
+__device__ __forceinline__ void map_freeze(double *__restrict__ map_store, int32_t *__restrict__ map_n, int map_cap, int b,
+                                           const double *__restrict__ kfp, const double *__restrict__ kfv, int n,
+                                           int scan, const double *__restrict__ locals)
+{
+    const int slot = map_n[b];
+    if (slot >= map_cap) return;                          // ring full: the keyframe is dropped, count stays at cap
+    double *d = map_store + ((size_t)b * map_cap + slot) * MAP_SLOT;
+    for (int j = threadIdx.x; j < 2 * n; j += blockDim.x) d[8 + j] = locals[j];
+    if (threadIdx.x == 0) {
+        d[0] = kfp[0]; d[1] = kfp[1]; d[2] = kfp[2];
+        d[3] = kfv[0]; d[4] = kfv[1]; d[5] = kfv[2];
+        d[6] = (double)n; d[7] = (double)scan;
+    }
+}
+
+// host-initiated keyframe replacement (roam_engine_set_features): freeze the live keyframe unless the step that
+// has just run created it (then g4 already froze its predecessor and the caller is amending the new one)
+__global__ __launch_bounds__(256) void map_freeze_kernel(double *__restrict__ map_store, int32_t *__restrict__ map_n, int map_cap,
+                                                         int b, const double *__restrict__ kf_pose,
+                                                         const double *__restrict__ kf_vel, const int32_t *__restrict__ feat_n,
+                                                         const int32_t *__restrict__ kf_scan, const double *__restrict__ kf_und,
+                                                         const int32_t *__restrict__ kf_live, const int32_t *__restrict__ kf_fresh)
+{
+    if (!kf_live[b] || kf_fresh[b]) return;
+    const int slot = map_n[b];
+    map_freeze(map_store, map_n, map_cap, b, kf_pose + 3 * b, kf_vel + 3 * b, feat_n[b], kf_scan[b], kf_und + (size_t)b * KS * 2);
+    __syncthreads();
+    if (threadIdx.x == 0 && slot < map_cap) map_n[b] = slot + 1;
+}
+
 // G4: pose / velocity update, keyframe criteria (Mapping.py:149-174, RawROAMSystem.py:250-271),
 //     possible_kf.updateInfo undistortion (Mapping.py:65), result record
 __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, const double *__restrict__ lm_out,
@@ -224,7 +265,10 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
                                                         const double *__restrict__ p_jt, const int32_t *__restrict__ in_n,
                                                         const int32_t *__restrict__ good_n, int32_t *__restrict__ feat_n,
                                                         const int32_t *__restrict__ peaks_n, const int32_t *__restrict__ cq_flags,
-                                                        roam_lane_result *__restrict__ res)
+                                                        roam_lane_result *__restrict__ res, const int32_t *__restrict__ scan_idx,
+                                                        double *__restrict__ kf_vel, int32_t *__restrict__ kf_scan,
+                                                        int32_t *__restrict__ kf_fresh, const int32_t *__restrict__ kf_live,
+                                                        double *__restrict__ map_store, int32_t *__restrict__ map_n, int map_cap)
 {
     __shared__ double np_[3], nv_[3];
     __shared__ int newkf;
@@ -264,6 +308,9 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
     }
     __syncthreads();
     const double v0 = nv_[0], v1 = nv_[1], v2 = nv_[2];
+    // a keyframe that is replaced keeps its final state (pose, creation velocity, pruned locals) in the map
+    const int mslot = (newkf && map_cap > 0 && kf_live[b]) ? map_n[b] : -1;
+    if (mslot >= 0) map_freeze(map_store, map_n, map_cap, b, kf_pose + 3 * b, kf_vel + 3 * b, n, kf_scan[b], kf_und_tmp + (int64_t)b * KS * 2);
     for (int j = t; j < n; j += 256) {
         const int64_t o = (int64_t)b * KS + j;
         if (newkf) {
@@ -280,7 +327,13 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
     if (t == 0) {
         pose[3 * b] = np_[0]; pose[3 * b + 1] = np_[1]; pose[3 * b + 2] = np_[2];
         vel[3 * b] = v0; vel[3 * b + 1] = v1; vel[3 * b + 2] = v2;
-        if (newkf) { kf_pose[3 * b] = np_[0]; kf_pose[3 * b + 1] = np_[1]; kf_pose[3 * b + 2] = np_[2]; }
+        if (newkf) {
+            kf_pose[3 * b] = np_[0]; kf_pose[3 * b + 1] = np_[1]; kf_pose[3 * b + 2] = np_[2];
+            kf_vel[3 * b] = v0; kf_vel[3 * b + 1] = v1; kf_vel[3 * b + 2] = v2;
+            kf_scan[b] = scan_idx[b];
+            if (mslot >= 0 && mslot < map_cap) map_n[b] = mslot + 1;
+        }
+        kf_fresh[b] = newkf;
         feat_n[b] = n;
     }
 }
@@ -331,6 +384,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     e->cfg = *cfg;
     const int B = e->B = cfg->lanes;
     e->lane_k.assign(B, 0);
+    e->last_scan.assign(B, -1);
     e->W = 2 * (cfg->clip / 2);
     e->stage_cap = (cfg->clip + 1) / 2;
     pyr_desc_init(&e->pd, e->W, e->W);
@@ -365,6 +419,8 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->kab_out, (size_t)B * 6);
     ok = ok && dalloc(ctx, e, &e->in_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->kf_pose, (size_t)B * 3);
+    ok = ok && dalloc(ctx, e, &e->kf_vel, (size_t)B * 3) && dalloc(ctx, e, &e->kf_scan, (size_t)B) && dalloc(ctx, e, &e->kf_fresh, (size_t)B) &&
+         dalloc(ctx, e, &e->kf_live, (size_t)B) && dalloc(ctx, e, &e->map_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->kf_und, (size_t)B * KS * 2);
     ok = ok && dalloc(ctx, e, &e->kf_und_tmp, (size_t)B * KS * 2);
     ok = ok && dalloc(ctx, e, &e->pose, (size_t)B * 3);
@@ -448,11 +504,15 @@ static WarpSrc pool_warp_src(Engine *e, const int32_t *lane_index)
     return s;
 }
 
-int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, int32_t K)
+static int32_t set_features_impl(roam_ctx *ctx, Engine *e, int32_t lane, const float *pts, int32_t K, int32_t kf_scan)
 {
-    ENGINE();
-    ARG_CHECK(ctx, lane >= 0 && lane < e->B && K >= 0 && K <= KS && (K == 0 || pts));
     float *f = e->feat + (size_t)lane * KS * 2;
+    // f1: the keyframe this call replaces goes to the lane's map ring first (device-side decision, see the kernel)
+    if (e->map_cap > 0) {
+        hipLaunchKernelGGL(map_freeze_kernel, dim3(1), dim3(256), 0, ctx->stream, e->map_store, e->map_n, e->map_cap, lane,
+                           e->kf_pose, e->kf_vel, e->feat_n, e->kf_scan, e->kf_und, e->kf_live, e->kf_fresh);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     e->lane_k[lane] = K;
     if (K > 0) HIP_TRY(ctx, hipMemcpyAsync(f, pts, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(e->feat_n + lane, &K, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -460,10 +520,83 @@ int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, 
     // kf pose = latest pose, kf locals = undistort(velocity, centred features)
     HIP_TRY(ctx, hipMemcpyAsync(e->kf_pose + 3 * (size_t)lane, e->pose + 3 * (size_t)lane, sizeof(double) * 3,
                                 hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(e->kf_vel + 3 * (size_t)lane, e->vel + 3 * (size_t)lane, sizeof(double) * 3,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    const int32_t one = 1;
+    HIP_TRY(ctx, hipMemcpyAsync(e->kf_live + lane, &one, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (kf_scan >= 0) HIP_TRY(ctx, hipMemcpyAsync(e->kf_scan + lane, &kf_scan, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     if (K > 0) {
         hipLaunchKernelGGL(lane_kf_reset_kernel, dim3((K + 255) / 256), dim3(256), 0, ctx->stream, f, K,
                            e->vel + 3 * (size_t)lane, e->kf_und + (size_t)lane * KS * 2);
         HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ROAM_OK;
+}
+
+int32_t roam_engine_set_features(roam_ctx *ctx, int32_t lane, const float *pts, int32_t K)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && K >= 0 && K <= KS && (K == 0 || pts));
+    return set_features_impl(ctx, e, lane, pts, K, e->last_scan[lane]);
+}
+
+int32_t roam_engine_map_reserve(roam_ctx *ctx, int32_t keyframes_per_lane)
+{
+    ENGINE();
+    ARG_CHECK(ctx, keyframes_per_lane > 0 && keyframes_per_lane <= 4096);
+    if (e->map_cap > 0) { ROAM_SET_ERR(ctx, "engine: the keyframe map is already reserved (%d per lane)", e->map_cap); return ROAM_E_STATE; }
+    if (!dalloc(ctx, e, &e->map_store, (size_t)e->B * keyframes_per_lane * MAP_SLOT)) return ROAM_E_HIP;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    e->map_cap = keyframes_per_lane;
+    return ROAM_OK;
+}
+
+int32_t roam_engine_map_count(roam_ctx *ctx, int32_t lane, int32_t *count)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && count);
+    int32_t v[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(&v[0], e->map_n + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&v[1], e->kf_live + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count = v[0] + (v[1] ? 1 : 0);                 // frozen keyframes + the live one
+    return ROAM_OK;
+}
+
+int32_t roam_engine_map_get(roam_ctx *ctx, int32_t lane, int32_t index, double *pose3, double *vel3, double *locals_xy,
+                            int32_t cap_pts, int32_t *n_out, int32_t *scan_out)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && index >= 0 && pose3 && vel3 && n_out && scan_out && cap_pts >= 0 && (cap_pts == 0 || locals_xy));
+    int32_t v[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(&v[0], e->map_n + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&v[1], e->kf_live + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int frozen = v[0];
+    if (index < frozen) {
+        const double *src = e->map_store + ((size_t)lane * e->map_cap + index) * MAP_SLOT;
+        double hdr[8];
+        HIP_TRY(ctx, hipMemcpyAsync(hdr, src, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const int n = (int)hdr[6];
+        for (int i = 0; i < 3; i++) { pose3[i] = hdr[i]; vel3[i] = hdr[3 + i]; }
+        *n_out = n; *scan_out = (int32_t)hdr[7];
+        if (n > cap_pts) { ROAM_SET_ERR(ctx, "map_get: keyframe has %d points, capacity %d", n, cap_pts); return ROAM_E_CAPACITY; }
+        if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(locals_xy, src + 8, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (index == frozen && v[1]) {           // the live keyframe
+        int32_t n = 0, sc = -1;
+        HIP_TRY(ctx, hipMemcpyAsync(pose3, e->kf_pose + 3 * (size_t)lane, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(vel3, e->kf_vel + 3 * (size_t)lane, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&n, e->feat_n + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&sc, e->kf_scan + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *n_out = n; *scan_out = sc;
+        if (n > cap_pts) { ROAM_SET_ERR(ctx, "map_get: keyframe has %d points, capacity %d", n, cap_pts); return ROAM_E_CAPACITY; }
+        if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(locals_xy, e->kf_und + (size_t)lane * KS * 2, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        ROAM_SET_ERR(ctx, "map_get: lane %d holds %d keyframes, index %d", lane, frozen + (v[1] ? 1 : 0), index);
+        return ROAM_E_ARG;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
@@ -483,7 +616,7 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
     HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane, pose3, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(e->vel + 3 * (size_t)lane, zero, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return roam_engine_set_features(ctx, lane, pts, K);
+    return set_features_impl(ctx, e, lane, pts, K, pool_idx);
 }
 
 int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
@@ -492,6 +625,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     ARG_CHECK(ctx, scan_idx);
     const int B = e->B;
     for (int b = 0; b < B; b++) ARG_CHECK(ctx, scan_idx[b] >= 0 && scan_idx[b] < e->cfg.pool_scans);
+    for (int b = 0; b < B; b++) e->last_scan[b] = scan_idx[b];
     hipStream_t st = ctx->stream;
     const roam_engine_cfg &c = e->cfg;
     const int nw = KS / 64;
@@ -549,7 +683,8 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
                        e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n,
-                       e->cq_flags, e->results);
+                       e->cq_flags, e->results, e->scan_idx, e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
+                       e->map_cap);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
     e->cur ^= 1;

@@ -58,6 +58,29 @@ class Engine:
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
         self.ctx.check(self.lib.roam_engine_set_features(self.ctx.h, int(lane), _ffi._ptr(pts), pts.shape[0]))
 
+    # ---- 8f-f1: device-resident keyframe map (Mapping.Map.keyframes)
+    def map_reserve(self, keyframes_per_lane: int = 16):
+        """keep every keyframe of every lane in HBM (call once, before the first init_lane)"""
+        self.ctx.check(self.lib.roam_engine_map_reserve(self.ctx.h, int(keyframes_per_lane)))
+
+    def map_count(self, lane: int) -> int:
+        n = C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_map_count(self.ctx.h, int(lane), C.byref(n)))
+        return n.value
+
+    def map_keyframe(self, lane: int, index: int) -> dict:
+        """keyframe `index` of the lane's map (0 = oldest, map_count-1 = live): pose, velocity at creation,
+        prunedUndistortedLocals (n, 2) in metres, pool scan it was created on"""
+        pose, vel = np.empty(3), np.empty(3)
+        loc = np.empty((_ffi.MAX_FEATURES, 2))
+        n, sc = C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_map_get(self.ctx.h, int(lane), int(index), _ffi._ptr(pose), _ffi._ptr(vel),
+                                                    _ffi._ptr(loc), loc.shape[0], C.byref(n), C.byref(sc)))
+        return dict(pose=pose, velocity=vel, prunedUndistortedLocals=loc[:n.value].copy(), scan=sc.value)
+
+    def map_keyframes(self, lane: int):
+        return [self.map_keyframe(lane, i) for i in range(self.map_count(lane))]
+
     def step(self, scan_idx):
         idx = np.ascontiguousarray(scan_idx, np.int32)
         assert idx.shape == (self.lanes,)

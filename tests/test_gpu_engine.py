@@ -207,3 +207,57 @@ def test_engine_lane_batches_are_independent(sequences):
             assert np.array_equal(eng.lane_peaks(b), eng.lane_peaks(r)), (t, b)
             for lvl in range(4):
                 assert np.array_equal(eng.lane_image(b, lvl), eng.lane_image(r, lvl)), (t, b, lvl)
+
+
+def test_engine_keyframe_map_matches_oracle(sequences):
+    """8f-f1: every keyframe the tracker replaces (pose criterion inside the step, or retrack through the host)
+    must appear in the device-resident map with the state the oracle's Keyframe object had when it was replaced
+    (pose, creation velocity, pruned undistorted locals); the last entry is the live keyframe."""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    # 0.8-1.6 m per scan: the 2 m keyframe criterion fires every second or third frame
+    recs, poses, feat = synth.make_sequence(11, 8, n_movers=0, distortion=True)
+    T = len(recs)
+    ctx = _ffi.Context(0)
+    eng = Engine(2, T, ctx=ctx)
+    eng.map_reserve(8)
+    for t in range(T):
+        eng.upload_scan(t, recs[t])
+    feat0 = feat[:90]
+    pipes = []
+    for b in range(2):
+        eng.init_lane(b, 0, feat0, poses[0])
+        pipes.append(oracle.OdometryPipeline(recs[0], feat0, poses[0], detect=lambda cart: oracle.getFeatures(cart)[0]))
+    assert eng.map_count(0) == 1 and eng.map_keyframe(0, 0)["scan"] == 0
+    frozen = [[], []]
+
+    def same(kf, okf, tag):
+        assert np.abs(kf["pose"][:2] - okf.pose[:2]).max() <= POS_TOL and abs(kf["pose"][2] - okf.pose[2]) <= ANG_TOL, tag
+        assert np.abs(kf["velocity"] - np.asarray(okf.velocity)).max() <= 1e-4, tag
+        assert kf["prunedUndistortedLocals"].shape == okf.prunedUndistortedLocals.shape, tag
+        assert np.abs(kf["prunedUndistortedLocals"] - okf.prunedUndistortedLocals).max() <= 1e-4, tag
+
+    n_new = 0
+    for t in range(1, T):
+        before = [p.old_kf for p in pipes]
+        eng.step([t, t])
+        res = eng.results()
+        for b in range(2):
+            want = pipes[b].step(recs[t])
+            assert res[b]["retrack"] == bool(want["retrack"]) and res[b]["new_keyframe"] == bool(want["new_keyframe"]), (t, b)
+            if want["new_keyframe"]:
+                frozen[b].append(before[b])
+                n_new += 1
+            if res[b]["retrack"]:
+                eng.retrack_lane(b, t)
+            assert eng.map_count(b) == len(frozen[b]) + 1, (t, b)
+            same(eng.map_keyframe(b, len(frozen[b])), pipes[b].old_kf, (t, b, "live"))
+    assert n_new >= 2
+    for b in range(2):
+        kfs = eng.map_keyframes(b)
+        assert len(kfs) == len(frozen[b]) + 1
+        for i, okf in enumerate(frozen[b]):
+            same(kfs[i], okf, (b, i))
+        assert [k["scan"] for k in kfs] == sorted(k["scan"] for k in kfs)
+    eng.close()
+    ctx.close()
