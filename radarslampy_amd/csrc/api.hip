@@ -23,14 +23,9 @@ int32_t roam_create(int32_t device_id, roam_ctx **out)
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
     ctx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
-    {   // side stream (polar peaks) at the HIGHEST priority: the peak kernel is short (0.8 ms of work per
-        // 1024 scans) but its 21 KB workgroups only fit next to the warp's when one of those retires, so at
-        // low priority it trickled on until it overlapped the register-bound LM solve and slowed that down
-        // (measured: LM 1.85 ms -> 1.05 ms, step 9.3 -> 8.85 ms with the priority raised)
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
-        if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
-    }
+    // front-end stream: peaks, warp and pyramid of a step run here so that they can overlap the back end
+    // (KLT ... LM) of the previous step; equal priority measured best once the two stages are pipelined
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
     if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fence, hipEventDisableTiming) != hipSuccess) {
         delete ctx; return ROAM_E_HIP;

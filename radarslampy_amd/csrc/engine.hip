@@ -33,12 +33,16 @@ struct Engine {
     PyrDesc pd;
     size_t rec_bytes = 0;
     uint8_t *pool = nullptr;
-    uint8_t *pyr[2] = {nullptr, nullptr};
+    uint8_t *pyr[3] = {nullptr, nullptr, nullptr};   // ring: previous / current / the one the front end of the next step fills
     uint32_t *warp_map = nullptr;       // W x W sampling map (geometry only)
     int cur = 0;                        // pyr[cur] = previous image pyramids
     uint16_t *row_stage = nullptr;
-    int32_t *row_count = nullptr, *peaks_out = nullptr, *peaks_n = nullptr;
-    int32_t *scan_idx = nullptr;
+    int32_t *row_count = nullptr;
+    int32_t *peaks_out[2] = {nullptr, nullptr}, *peaks_n[2] = {nullptr, nullptr};   // double-buffered by step parity
+    int32_t *scan_idx[2] = {nullptr, nullptr};
+    int32_t *scan_host = nullptr;       // pinned staging of the scan indices (2 x B)
+    int pk = 0;                         // parity of the latest step (valid peak / scan-index buffers)
+    int64_t nstep = 0;
     float *feat = nullptr;              // B x KS x 2
     int32_t *feat_n = nullptr;
     float *klt_next = nullptr, *klt_err = nullptr;
@@ -65,7 +69,8 @@ struct Engine {
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
     roam_lane_result *results = nullptr;
     hipEvent_t ev[ST_COUNT + 1];
-    hipEvent_t ev_fork, ev_join, ev_pk0, ev_pk1;   // side-stream fork / join + its own timing pair
+    hipEvent_t ev_fork, ev_join, ev_pk0, ev_pk1;   // front-stream fork / join + the peak kernel's timing pair
+    hipEvent_t ev_klt[2], ev_g4[2];                // back-end milestones the front end of step N+2 waits for
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
     int kmax() const { int m = 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
@@ -362,7 +367,9 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (void *p : e->allocs) hipFree(p);
-    if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1); }
+    if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
+                    for (int i = 0; i < 2; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } }
+    if (e->scan_host) hipHostFree(e->scan_host);
     hipStreamSynchronize(ctx->stream2);
     delete e;
     ctx->engine = nullptr;
@@ -394,12 +401,18 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->pool, e->rec_bytes * cfg->pool_scans);
     ok = ok && dalloc(ctx, e, &e->pyr[0], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[1], (size_t)e->pd.lane_stride * B);
+    ok = ok && dalloc(ctx, e, &e->pyr[2], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->warp_map, (size_t)e->W * e->W);
     ok = ok && dalloc(ctx, e, &e->row_stage, (size_t)B * cfg->rows * e->stage_cap);
     ok = ok && dalloc(ctx, e, &e->row_count, (size_t)B * cfg->rows);
-    ok = ok && dalloc(ctx, e, &e->peaks_out, (size_t)B * cfg->peaks_cap * 2);
-    ok = ok && dalloc(ctx, e, &e->peaks_n, (size_t)B);
-    ok = ok && dalloc(ctx, e, &e->scan_idx, (size_t)B);
+    for (int i = 0; i < 2; i++) {
+        ok = ok && dalloc(ctx, e, &e->peaks_out[i], (size_t)B * cfg->peaks_cap * 2);
+        ok = ok && dalloc(ctx, e, &e->peaks_n[i], (size_t)B);
+        ok = ok && dalloc(ctx, e, &e->scan_idx[i], (size_t)B);
+    }
+    if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->scan_host), sizeof(int32_t) * 2 * (size_t)B, hipHostMallocDefault) != hipSuccess) {
+        ROAM_SET_ERR(ctx, "engine: hipHostMalloc failed"); ok = false;
+    }
     ok = ok && dalloc(ctx, e, &e->feat, (size_t)B * KS * 2);
     ok = ok && dalloc(ctx, e, &e->feat_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->klt_next, (size_t)B * KS * 2);
@@ -439,7 +452,9 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     }
     if (hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess ||
-        hipEventCreate(&e->ev_pk0) != hipSuccess || hipEventCreate(&e->ev_pk1) != hipSuccess) {
+        hipEventCreate(&e->ev_pk0) != hipSuccess || hipEventCreate(&e->ev_pk1) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_klt[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_klt[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_g4[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_g4[1], hipEventDisableTiming) != hipSuccess) {
         ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
     e->ev_ok = true;
@@ -630,27 +645,38 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     const roam_engine_cfg &c = e->cfg;
     const int nw = KS / 64;
     const int KM = e->kmax();          // host-known bound: feature counts only shrink between (re)seeds
-    if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_up, 0)); e->uploads_pending = false; }
-    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx, scan_idx, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, st));
-    uint8_t *prev = e->pyr[e->cur], *next = e->pyr[e->cur ^ 1];
-
-    // polar peaks (a2) depend only on the raw scan: they run on the side stream, concurrently with
-    // the warp -> pyramid -> KLT -> ... chain, and are joined before the per-lane result record
-    hipStream_t s2 = ctx->stream2;
-    HIP_TRY(ctx, hipEventRecord(e->ev_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(s2, e->ev_fork, 0));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, s2));
-    PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};
-    HIP_TRY(ctx, launch_peaks(s2, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, s2));
-    HIP_TRY(ctx, hipEventRecord(e->ev_join, s2));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], st));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], st));
-    HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], st));
-    HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
+    // Two-stage pipeline across steps.  FRONT END (peaks, warp, pyramid) depends only on the raw scan: it runs
+    // on its own stream and may start while the BACK END (KLT ... LM, g4) of the previous step is still busy -
+    // that back end is latency-bound (the LM solve holds registers, not issue slots).  Three pyramid buffers
+    // (previous / current / being filled) and parity-indexed peak and scan-index buffers keep the two apart:
+    //   front(N) waits for KLT(N-2)  - the pyramid it overwrites was that tracker's "previous" image
+    //   front(N) waits for g4(N-2)   - peak counts / scan indices of the same parity are read by that kernel
+    //   KLT(N)   waits for front(N)
+    hipStream_t sf = ctx->stream2;
+    const int pb = (int)(e->nstep & 1);
+    uint8_t *prev = e->pyr[e->cur], *next = e->pyr[(e->cur + 1) % 3];
+    HIP_TRY(ctx, hipStreamWaitEvent(sf, e->ev_klt[pb], 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(sf, e->ev_g4[pb], 0));
+    // (lane initialisation, retracks and synchronous uploads finish on the host before a step is enqueued)
+    if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(sf, ctx->ev_up, 0)); e->uploads_pending = false; }
+    int32_t *hs = e->scan_host + (size_t)pb * B;
+    if (e->nstep >= 2) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[pb]));   // the staging slot's last copy has long been consumed
+    for (int b = 0; b < B; b++) hs[b] = scan_idx[b];
+    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, sf));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sf));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sf));
+    PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[pb]};
+    HIP_TRY(ctx, launch_peaks(sf, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sf));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], sf));
+    HIP_TRY(ctx, launch_warp_gather(sf, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], sf));
+    HIP_TRY(ctx, launch_build_pyramid(sf, next, e->pd, B));
+    HIP_TRY(ctx, hipEventRecord(e->ev_join, sf));                         // end of the front end
+    HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
     HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KM, KS, B, e->klt_next, e->klt_status, e->klt_err));
+    HIP_TRY(ctx, hipEventRecord(e->ev_klt[pb], st));
     hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,
                        e->good_old, e->good_new, e->good_idx, e->good_n);
     HIP_TRY(ctx, hipGetLastError());
@@ -680,14 +706,16 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
-                       e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n,
-                       e->cq_flags, e->results, e->scan_idx, e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
+                       e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n[pb],
+                       e->cq_flags, e->results, e->scan_idx[pb], e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
                        e->map_cap);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
-    e->cur ^= 1;
+    HIP_TRY(ctx, hipEventRecord(e->ev_g4[pb], st));
+    e->cur = (e->cur + 1) % 3;
+    e->pk = pb;
+    e->nstep++;
     e->stepped = true;
     return ROAM_OK;
 }
@@ -722,13 +750,13 @@ int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_
     ENGINE();
     ARG_CHECK(ctx, lane >= 0 && lane < e->B && out && n_out && cap >= 0);
     int32_t n = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n, e->peaks_n + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&n, e->peaks_n[e->pk] + lane, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = n;
     int64_t m = n < cap ? n : cap;
     if (m > e->cfg.peaks_cap) m = e->cfg.peaks_cap;
     if (m > 0) {
-        HIP_TRY(ctx, hipMemcpyAsync(out, e->peaks_out + (size_t)lane * e->cfg.peaks_cap * 2, sizeof(int32_t) * 2 * (size_t)m,
+        HIP_TRY(ctx, hipMemcpyAsync(out, e->peaks_out[e->pk] + (size_t)lane * e->cfg.peaks_cap * 2, sizeof(int32_t) * 2 * (size_t)m,
                                     hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -765,7 +793,8 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;
-        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev_pk0, e->ev_pk1));   // side stream (overlapped)
+        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev_pk0, e->ev_pk1));   // front stream
+        else if (i == ST_PYR) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[ST_PYR], e->ev_join));   // front stream, up to its last kernel
         else HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
         ms_out[i] = ms;
         if (names_out) names_out[i] = kStageNames[i];
@@ -785,7 +814,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     hipStream_t st = ctx->stream;
     const roam_engine_cfg &c = e->cfg;
     const int B = e->B;
-    uint8_t *next = e->pyr[e->cur ^ 1];       // not the live "previous" pyramid
+    uint8_t *next = e->pyr[(e->cur + 1) % 3];       // not the live "previous" pyramid
     double bytes = 0;
     hipEvent_t a, b;
     HIP_TRY(ctx, hipEventCreate(&a));
@@ -794,11 +823,11 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     HIP_TRY(ctx, hipEventRecord(a, st));
     for (int r = 0; r < reps; r++) {
         if (!strcmp(name, "warp_quantise")) {
-            HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx), B, c.rows, c.clip, next, e->pd.lane_stride));
+            HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx[e->pk]), B, c.rows, c.clip, next, e->pd.lane_stride));
             bytes = (double)B * ((double)c.rows * c.clip + (double)e->W * e->W);
         } else if (!strcmp(name, "ingest_peaks")) {
-            PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx};
-            hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out, c.peaks_cap, e->peaks_n);
+            PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[e->pk]};
+            hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[e->pk ^ 1], c.peaks_cap, e->peaks_n[e->pk ^ 1]);
             HIP_TRY(ctx, er);
             bytes = (double)B * ((double)c.rows * c.clip);
         } else if (!strcmp(name, "pyramid")) {

@@ -261,3 +261,39 @@ def test_engine_keyframe_map_matches_oracle(sequences):
         assert [k["scan"] for k in kfs] == sorted(k["scan"] for k in kfs)
     eng.close()
     ctx.close()
+
+
+def test_engine_pipelined_steps_match_synchronised_steps(sequences):
+    """The front end of step N+1 (peaks, warp, pyramid) may overlap the back end of step N when steps are enqueued
+    back to back.  Six steps without any host synchronisation in between must leave exactly the state that the same
+    six steps leave when the host reads the results after every step (poses, features, peaks, all pyramid levels)."""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(21, 7, n_movers=6, distortion=True)
+    T, B = len(recs), 40
+    ctx = _ffi.Context(0)
+
+    def run(sync_each_step):
+        eng = Engine(B, T, ctx=ctx)
+        for t in range(T):
+            eng.upload_scan(t, recs[t])
+        for b in range(B):
+            eng.init_lane(b, 0, feat[:200 + 3 * b], poses[0])
+        for t in range(1, T):
+            eng.step([t] * B)
+            if sync_each_step:
+                eng.results()
+        res = eng.results()
+        out = dict(pose=np.array([r["pose"] for r in res]), vel=np.array([r["velocity"] for r in res]),
+                   counts=np.array([[r["n_tracked"], r["n_good"], r["n_inliers"], r["n_peaks"], r["lm_nfev"]] for r in res]),
+                   feats=[eng.lane_features(b) for b in (0, 7, 39)], peaks=[eng.lane_peaks(b) for b in (0, 7, 39)],
+                   imgs=[eng.lane_image(b, lvl) for b in (0, 39) for lvl in range(4)])
+        eng.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["vel"], b["vel"]) and np.array_equal(a["counts"], b["counts"])
+    for k in ("feats", "peaks", "imgs"):
+        for x, y in zip(a[k], b[k]):
+            assert np.array_equal(x, y), k
+    ctx.close()
