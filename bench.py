@@ -173,23 +173,29 @@ def main():
     if rank == 0:
         pairs = B * args.steps * world
         value = pairs / dt
-        # ---- roofline of the dominant HBM-streaming kernel: each candidate is re-launched over all lanes
-        # in isolation and timed with HIP events on the engine's own stream (roam_engine_time_kernel)
-        iso = {k: eng.time_kernel(k, args.kernel_reps) for k in ("ingest_peaks", "warp_quantise", "pyramid")}
-        dom_stream = max(iso, key=lambda k: iso[k][0])
-        ms, algo_bytes = iso[dom_stream]
+        # ---- roofline of the dominant HBM-streaming kernel.  `avg_launch_ms` is the kernel's average launch duration
+        # over the K timed steps, from HIP event pairs recorded on the stream it runs on (roam_engine_kernel_avg; no
+        # synchronisation inside the timed region).  In the pipelined engine other kernels share the GPU during
+        # those launches, so the same kernels are also re-launched alone after the timed region
+        # (roam_engine_time_kernel) and reported as `isolated_*`.
+        names = ("ingest_peaks", "warp_quantise", "pyramid")
+        live = {k: eng.kernel_avg(k, args.steps)[0] for k in names}
+        iso = {k: eng.time_kernel(k, args.kernel_reps) for k in names}
+        dom_stream = max(live, key=lambda k: live[k])
+        ms, algo_bytes = live[dom_stream], iso[dom_stream][1]
         achieved = algo_bytes / (ms * 1e-3) / 1e9
         # HBM traffic of that kernel from the committed PMC passes (profiles/pmc_run.sh), per launch
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_kernel", "pyramid": "pyr_down_rows_kernel"}[dom_stream]
+            kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_wave_kernel", "pyramid": "pyr_down_rows_kernel"}[dom_stream]
             traffic = tj["kernels"][kname]["traffic_bytes_per_scan"] * B
         except Exception:
             pass
         roofline = {"bound": "hbm", "kernel": dom_stream, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                    "in_step_kernel_ms": {k: round(v, 4) for k, v in live.items()},
                     "isolated_kernel_ms": {k: round(v[0], 4) for k, v in iso.items()},
                     "isolated_kernel_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in iso.items()}}
         # whole-path view: SURVEY 8d B_min = 13.07 MB per steady pair

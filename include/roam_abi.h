@@ -218,6 +218,10 @@ int32_t roam_engine_map_get(roam_ctx *ctx, int32_t lane, int32_t index, double *
  * names_out receives n pointers to static strings. */
 int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap,
                                 int32_t *n);
+/* average in-step launch time (ms) of a front-end kernel ("ingest_peaks" | "warp_quantise" | "pyramid") over the
+ * last `last_steps` steps (<= 64), from HIP event pairs recorded on the stream the kernel runs on; no
+ * synchronisation happens inside the steps themselves */
+int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_steps, float *avg_ms, int32_t *n_used);
 /* time `reps` launches of the dominant streaming kernel (warp+quantise of all lanes) with
  * HIP events on the context stream; returns average ms per launch. */
 int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms,

@@ -12,6 +12,7 @@
 // (Mapping.py:37-66,97-125,149-174).  Scan pairs of different lanes are independent, so the
 // batch dimension is what fills the 256 CUs; within a lane the chain is sequential.
 #include "roam_internal.h"
+#include <algorithm>
 #include <new>
 
 #define KS ROAM_MAX_FEATURES
@@ -71,6 +72,11 @@ struct Engine {
     hipEvent_t ev[ST_COUNT + 1];
     hipEvent_t ev_fork, ev_join, ev_pk0, ev_pk1;   // front-stream fork / join + the peak kernel's timing pair
     hipEvent_t ev_klt[2], ev_g4[2];                // back-end milestones the front end of step N+2 waits for
+    // per-step boundaries of the three front-end kernels (before peaks | peaks/warp | warp/pyramid | after pyramid),
+    // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
+    // region without synchronising inside it (roam_engine_kernel_avg)
+    hipEvent_t tr_ev[64][4];
+    bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
     int kmax() const { int m = 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
@@ -370,6 +376,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
                     for (int i = 0; i < 2; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } }
     if (e->scan_host) hipHostFree(e->scan_host);
+    if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
     delete e;
     ctx->engine = nullptr;
@@ -458,6 +465,10 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
     e->ev_ok = true;
+    for (auto &row : e->tr_ev)
+        for (auto &ev : row)
+            if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    e->tr_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
@@ -663,15 +674,20 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     if (e->nstep >= 2) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[pb]));   // the staging slot's last copy has long been consumed
     for (int b = 0; b < B; b++) hs[b] = scan_idx[b];
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, sf));
+    hipEvent_t *tr = e->tr_ev[e->nstep & 63];
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sf));
     HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sf));
+    HIP_TRY(ctx, hipEventRecord(tr[0], sf));
     PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[pb]};
     HIP_TRY(ctx, launch_peaks(sf, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
     HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sf));
+    HIP_TRY(ctx, hipEventRecord(tr[1], sf));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], sf));
     HIP_TRY(ctx, launch_warp_gather(sf, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride));
+    HIP_TRY(ctx, hipEventRecord(tr[2], sf));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], sf));
     HIP_TRY(ctx, launch_build_pyramid(sf, next, e->pd, B));
+    HIP_TRY(ctx, hipEventRecord(tr[3], sf));
     HIP_TRY(ctx, hipEventRecord(e->ev_join, sf));                         // end of the front end
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
@@ -800,6 +816,28 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
         if (names_out) names_out[i] = kStageNames[i];
     }
     *n = ST_COUNT;
+    return ROAM_OK;
+}
+
+// average launch time of one front-end kernel over the last `last_steps` steps (at most 64), from the event
+// pairs recorded on the stream the kernel ran on - the live, in-step duration (other kernels may share the GPU)
+int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_steps, float *avg_ms, int32_t *n_used)
+{
+    ENGINE();
+    ARG_CHECK(ctx, name && last_steps >= 1 && avg_ms && n_used);
+    int k = !strcmp(name, "ingest_peaks") ? 0 : (!strcmp(name, "warp_quantise") ? 1 : (!strcmp(name, "pyramid") ? 2 : -1));
+    if (k < 0) { ROAM_SET_ERR(ctx, "unknown kernel '%s'", name); return ROAM_E_ARG; }
+    if (!e->stepped) { ROAM_SET_ERR(ctx, "run a step first"); return ROAM_E_STATE; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n = std::min<int64_t>(std::min<int64_t>(last_steps, e->nstep), 64);
+    double sum = 0;
+    for (int64_t i = e->nstep - n; i < e->nstep; i++) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->tr_ev[i & 63][k], e->tr_ev[i & 63][k + 1]));
+        sum += ms;
+    }
+    *avg_ms = (float)(sum / (double)n);
+    *n_used = (int32_t)n;
     return ROAM_OK;
 }
 

@@ -155,6 +155,12 @@ class Engine:
         self.ctx.check(self.lib.roam_engine_stage_times(self.ctx.h, ms, names, 16, C.byref(n)))
         return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
+    def kernel_avg(self, name: str, last_steps: int):
+        """(average in-step launch time in ms, steps averaged) of a front-end kernel over the last steps"""
+        ms, n = C.c_float(0), C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_kernel_avg(self.ctx.h, name.encode(), int(last_steps), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def time_kernel(self, name: str, reps: int = 20):
         ms = C.c_float(0)
         by = C.c_double(0)
