@@ -1,12 +1,16 @@
 // Batched, device-resident scan-pair engine.
 //
-// B independent sequences ("lanes") live in HBM: the raw Oxford records (pool), two
-// u8 pyramids per lane (previous / current, ping-pong), the tracked feature set, the
-// keyframe state and the poses.  One roam_engine_step() advances EVERY lane by one scan
-// pair with ~15 kernel launches on one stream and no host round trip:
-//   ingest+peaks -> warp+quantise -> pyramid -> KLT -> (status & err<10) compaction ->
-//   consistency graph -> max clique -> inlier compaction + keyframe pruning + p_w / p_jt ->
-//   Kabsch -> initial transform -> motion-distortion LM -> pose / keyframe bookkeeping.
+// B independent sequences ("lanes") live in HBM: the raw Oxford records (pool), a ring of
+// three u8 pyramids per lane (previous / current / being filled), the tracked feature set, the
+// keyframe state (+ optionally every past keyframe, 8f-f1) and the poses.  One
+// roam_engine_step() advances EVERY lane by one scan pair with ~15 kernel launches and no host
+// round trip, in two pipelined stages:
+//   front end (own stream; depends only on the raw scan):  ingest+peaks -> warp+quantise -> pyramid
+//   back end:  KLT -> (status & err<10) compaction -> consistency graph -> max clique ->
+//              inlier compaction + keyframe pruning + p_w / p_jt -> Kabsch -> initial transform ->
+//              motion-distortion LM -> pose / keyframe bookkeeping
+// so that when steps are enqueued back to back the front end of step N+1 overlaps the
+// (latency-bound) back end of step N.
 // It restates the body of RawROAMSystem.run's loop (reference RawROAMSystem.py:162-298)
 // without the plotting, Tracker.track (Tracker.py:35-106) and the Keyframe bookkeeping
 // (Mapping.py:37-66,97-125,149-174).  Scan pairs of different lanes are independent, so the
@@ -70,7 +74,7 @@ struct Engine {
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
     roam_lane_result *results = nullptr;
     hipEvent_t ev[ST_COUNT + 1];
-    hipEvent_t ev_fork, ev_join, ev_pk0, ev_pk1;   // front-stream fork / join + the peak kernel's timing pair
+    hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[2], ev_g4[2];                // back-end milestones the front end of step N+2 waits for
     // per-step boundaries of the three front-end kernels (before peaks | peaks/warp | warp/pyramid | after pyramid),
     // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
@@ -373,7 +377,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (void *p : e->allocs) hipFree(p);
-    if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
+    if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
                     for (int i = 0; i < 2; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } }
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
@@ -458,7 +462,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     for (auto &ev : e->ev) {
         if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     }
-    if (hipEventCreate(&e->ev_fork) != hipSuccess || hipEventCreate(&e->ev_join) != hipSuccess ||
+    if (hipEventCreate(&e->ev_join) != hipSuccess ||
         hipEventCreate(&e->ev_pk0) != hipSuccess || hipEventCreate(&e->ev_pk1) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_klt[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_klt[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_g4[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_g4[1], hipEventDisableTiming) != hipSuccess) {
