@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=1024, help="independent sequences resident per GPU")
+    ap.add_argument("--lanes", type=int, default=None, help="independent sequences resident per GPU (default 4096; 1024 with --h2d)")
     ap.add_argument("--frames", type=int, default=7, help="frames per synthetic sequence (played ping-pong)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences generated per rank")
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle (0 = skip)")
@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--h2d", action="store_true", help="stream every scan from pinned host memory over PCIe (double-buffered pool); reports the PCIe-inclusive rate")
     ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
     args = ap.parse_args()
+    if args.lanes is None:
+        args.lanes = 1024 if args.h2d else 4096
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
