@@ -218,7 +218,7 @@ __global__ __launch_bounds__(PK_T) void peaks_rows_kernel(PeakSrc src, int rows,
 // lane boundary, the rare longer run walks the LDS copy of the row.  Candidates, NumPy-ordered
 // sums (8 lanes per <=128-element leaf), threshold and both compactions stay inside the wavefront.
 #ifndef PKW_WAVES
-#define PKW_WAVES 2          // rows (wavefronts) per workgroup: small workgroups (10 KB LDS) slot in next to the warp's
+#define PKW_WAVES 1          // rows (wavefronts) per workgroup: 5 KB LDS workgroups slot in next to any other kernel's
 #endif
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 
