@@ -409,7 +409,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     e->rec_bytes = (size_t)cfg->rows * cfg->stride;
     const int nw = KS / 64;
     bool ok = true;
-    ok = ok && dalloc(ctx, e, &e->pool, e->rec_bytes * cfg->pool_scans);
+    ok = ok && dalloc(ctx, e, &e->pool, e->rec_bytes * cfg->pool_scans + 64);      // + slack: the warp stages its boxes with dword loads
     ok = ok && dalloc(ctx, e, &e->pyr[0], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[1], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[2], (size_t)e->pd.lane_stride * B);

@@ -202,29 +202,42 @@ template <int M> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, M * 0x55, 0xf, 0xf, true);
 }
 
-// stage the polar box of U consecutive scans (l, l+1, ...): wave wvs takes rows wvs, wvs+4, ...
+// stage the polar box of U consecutive scans (l, l+1, ...).  A wavefront covers FOUR box rows per load
+// instruction: 16 lanes per row, one misaligned dword (4 range bins) per lane, decoded to four floats and
+// written with one 16-byte LDS store (the LDS row pitch bp is a multiple of 4 floats).  wave wvs takes the row
+// groups wvs, wvs+4, ...; the U scans' loads are issued before the first is consumed.
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
 template <int U>
 __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t lane_stride,
                                          const int32_t *__restrict__ lane_index, int l, int64_t row_stride, int rows,
-                                         int cols, int mnx, int mny, int bw, int bh, int elems, int wvs, int lane,
+                                         int cols, int mnx, int mny, int bw, int bp, int bh, int elems, int wvs, int lane,
                                          float *__restrict__ bq)
 {
     int64_t so[U];
 #pragma unroll
     for (int u = 0; u < U; u++) so[u] = (lane_index ? (int64_t)lane_index[l + u] : (int64_t)(l + u)) * lane_stride;
-    for (int k = wvs; k < bh; k += 4) {
+    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+    for (int kg = 4 * wvs; kg < bh; kg += 16) {
+        const int k = min(kg + sub, bh - 1);              // clamped lanes rewrite the last row
         int r = mny + k - 1;
         if (r < 0) r += rows; else if (r >= rows) r -= rows;
         for (int cb = 0; cb < bw; cb += 64) {
-            const int c = min(cb + lane, bw - 1);         // clamped lanes rewrite the last column
-            const bool inr = mnx + c < cols;
-            const uint8_t *srow = sp + ((int64_t)r * row_stride + min(mnx + c, cols - 1));
-            float *drow = bq + (k * bw + c);
+            const int c = min(cb + c4, bp - 4);           // clamped lanes rewrite the last column group
+            const int x0 = mnx + c;                       // first range bin of this lane's dword
+            const uint8_t *srow = sp + ((int64_t)r * row_stride + x0);
+            float *drow = bq + (k * bp + c);
             uint32_t raw[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) raw[u] = srow[so[u]];
+            for (int u = 0; u < U; u++) raw[u] = *reinterpret_cast<const u32_a1 *>(srow + so[u]);
 #pragma unroll
-            for (int u = 0; u < U; u++) drow[u * elems] = inr ? code_to_f32(raw[u]) : 0.f;
+            for (int u = 0; u < U; u++) {
+                float4 v;
+                v.x = (x0 < cols) ? code_to_f32(raw[u] & 255u) : 0.f;
+                v.y = (x0 + 1 < cols) ? code_to_f32((raw[u] >> 8) & 255u) : 0.f;
+                v.z = (x0 + 2 < cols) ? code_to_f32((raw[u] >> 16) & 255u) : 0.f;
+                v.w = (x0 + 3 < cols) ? code_to_f32(raw[u] >> 24) : 0.f;
+                *reinterpret_cast<float4 *>(drow + u * elems) = v;
+            }
         }
     }
 }
@@ -289,12 +302,13 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
     const bool any = mxx >= 0;
     const int bw = mxx - mnx + 2, bh = mxy - mny + 2;
-    const int elems = bw * bh;
+    const int bp = (bw + 3) & ~3;                     // LDS pitch of a box row: whole 16-byte stores
+    const int elems = bp * bh;
     const bool use_box = any && (elems <= WG_BOX_ELEMS);
     int off0[4], off1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (use_box) { off0[j] = (iyv[j] - mny) * bw + (ixv[j] - mnx); off1[j] = off0[j] + bw; }
+        if (use_box) { off0[j] = (iyv[j] - mny) * bp + (ixv[j] - mnx); off1[j] = off0[j] + bp; }
         else {
             int r0 = iyv[j] - 1, r1 = iyv[j];
             if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
@@ -361,10 +375,10 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             const int rem = nq - qb;
             const uint8_t *sp = pool + payload_off;
             float *bq = box + qb * elems;
-            if (rem >= 8 && WG_FILL_U >= 8) { box_fill<8>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 8; }
-            else if (rem >= 4 && WG_FILL_U >= 4) { box_fill<4>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 4; }
-            else if (rem >= 2 && WG_FILL_U >= 2) { box_fill<2>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 2; }
-            else { box_fill<1>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bh, elems, wvs, lane, bq); qb += 1; }
+            if (rem >= 8 && WG_FILL_U >= 8) { box_fill<8>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 8; }
+            else if (rem >= 4 && WG_FILL_U >= 4) { box_fill<4>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 4; }
+            else if (rem >= 2 && WG_FILL_U >= 2) { box_fill<2>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 2; }
+            else { box_fill<1>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 1; }
         }
         __syncthreads();
         for (int q = 0; q < nq; q++) {
