@@ -359,31 +359,18 @@ hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, 
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
-// exact 64-bit wavefront sum, returned to every lane.  Every KLT iteration ends in two of these, so
-// their latency is the iteration's critical path: four DPP steps (quad xor 1, quad xor 2, half-row
-// mirror, row mirror - ~10 cycles each against ~100 for a ds_bpermute shuffle) leave the 16-lane row
-// sums in every lane, the four row sums are read as scalars.  Integer addition: the order is free.
-template <int CTRL> __device__ __forceinline__ long long dpp_move_ll(long long v)
+// Window sums whose 64-pixel partial sums fit in 32 bits: |Ix|, |Iy| <= 4080 (Scharr of u8, bilinear average),
+// |diff| <= 8160 (u8 << 5), so a 16-lane row (4 pixels per lane) stays below 64 * 8160 * 4080 = 2 130 739 200 < 2^31.
+// The four DPP steps then run on single registers (the adds fold into the DPP instruction) and only the four
+// row sums are widened to 64 bits, as scalars.  Exact integer arithmetic either way.
+__device__ __forceinline__ long long wave_sum_rows_i32(int v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xffffffffll), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, false);
-    return ((long long)hi << 32) | (unsigned int)lo;
-}
-
-__device__ __forceinline__ long long readlane_ll(long long v, int l)
-{
-    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
-    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
-    return ((long long)hi << 32) | (unsigned int)lo;
-}
-
-__device__ __forceinline__ long long wave_sum_ll(long long v)
-{
-    v += dpp_move_ll<0xB1>(v);       // quad_perm [1,0,3,2]
-    v += dpp_move_ll<0x4E>(v);       // quad_perm [2,3,0,1]
-    v += dpp_move_ll<0x141>(v);      // row_half_mirror
-    v += dpp_move_ll<0x140>(v);      // row_mirror
-    return (readlane_ll(v, 0) + readlane_ll(v, 16)) + (readlane_ll(v, 32) + readlane_ll(v, 48));
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);        // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);       // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);       // row_mirror
+    return ((long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16)) +
+           ((long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48));
 }
 
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
@@ -522,7 +509,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
         }
         __syncthreads();
         int Iv[4], Ix[4], Iy[4];
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
+        int pA11 = 0, pA12 = 0, pA22 = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) { Iv[q] = 0; Ix[q] = 0; Iy[q] = 0; }
         if (ry < KW) {
@@ -552,12 +539,12 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                     Iv[q] = DESCALE(ia[q] * iw00 + ia[q + 1] * iw01 + ib[q] * iw10 + ib[q + 1] * iw11, W_BITS - 5);
                     Ix[q] = DESCALE(xa[q] * iw00 + xa[q + 1] * iw01 + xb[q] * iw10 + xb[q + 1] * iw11, W_BITS);
                     Iy[q] = DESCALE(ya[q] * iw00 + ya[q + 1] * iw01 + yb[q] * iw10 + yb[q + 1] * iw11, W_BITS);
-                    sA11 += (long long)Ix[q] * Ix[q];
-                    sA12 += (long long)Ix[q] * Iy[q];
-                    sA22 += (long long)Iy[q] * Iy[q];
+                    pA11 += Ix[q] * Ix[q];
+                    pA12 += Ix[q] * Iy[q];
+                    pA22 += Iy[q] * Iy[q];
                 }
         }
-        sA11 = wave_sum_ll(sA11); sA12 = wave_sum_ll(sA12); sA22 = wave_sum_ll(sA22);
+        const long long sA11 = wave_sum_rows_i32(pA11), sA12 = wave_sum_rows_i32(pA12), sA22 = wave_sum_rows_i32(pA22);
         const float A11 = __fmul_rn(__ll2float_rn(sA11), FLT_SCALE);
         const float A12 = __fmul_rn(__ll2float_rn(sA12), FLT_SCALE);
         const float A22 = __fmul_rn(__ll2float_rn(sA22), FLT_SCALE);
@@ -589,7 +576,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                 __syncthreads();
             }
             const int jox = inx - tx0, joy = iny - ty0;
-            long long sb1 = 0, sb2 = 0;
+            int pb1 = 0, pb2 = 0;
             if (ry < KW) {
                 int ra[5], rb[5];
                 row5(joy + ry, jox + g4, ra);
@@ -599,11 +586,11 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                     if (pv_[q]) {
                         int jv = DESCALE(ra[q] * iw00 + ra[q + 1] * iw01 + rb[q] * iw10 + rb[q + 1] * iw11, W_BITS - 5);
                         int diff = jv - Iv[q];
-                        sb1 += (long long)diff * Ix[q];
-                        sb2 += (long long)diff * Iy[q];
+                        pb1 += diff * Ix[q];
+                        pb2 += diff * Iy[q];
                     }
             }
-            sb1 = wave_sum_ll(sb1); sb2 = wave_sum_ll(sb2);
+            const long long sb1 = wave_sum_rows_i32(pb1), sb2 = wave_sum_rows_i32(pb2);
             const float b1 = __fmul_rn(__ll2float_rn(sb1), FLT_SCALE);
             const float b2 = __fmul_rn(__ll2float_rn(sb2), FLT_SCALE);
             const float ddx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), D);
@@ -630,7 +617,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                 __syncthreads();
             }
             const int eox = iex - tx0, eoy = iey - ty0;
-            long long se = 0;
+            int pe = 0;
             if (ry < KW) {
                 int ra[5], rb[5];
                 row5(eoy + ry, eox + g4, ra);
@@ -640,10 +627,10 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
                     if (pv_[q]) {
                         int jv = DESCALE(ra[q] * iw00 + ra[q + 1] * iw01 + rb[q] * iw10 + rb[q + 1] * iw11, W_BITS - 5);
                         int diff = jv - Iv[q];
-                        se += diff < 0 ? -diff : diff;
+                        pe += diff < 0 ? -diff : diff;
                     }
             }
-            se = wave_sum_ll(se);
+            const long long se = wave_sum_rows_i32(pe);
             er = __fmul_rn(__ll2float_rn(se), 1.f / (float)(32 * KW * KW));
         }
     }
