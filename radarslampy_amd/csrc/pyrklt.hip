@@ -359,6 +359,9 @@ hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, 
 #define W_BITS 14
 #define DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+// All window products have operands of at most 15 bits (pixels <= 255, weights <= 2^14, |Ix|, |Iy| <= 4080, |diff| <= 8160):
+// they are written with __mul24 so that they compile to the full-rate v_mad_i32_i24 instead of the quarter-rate
+// 32-bit multiply.
 // Window sums whose 64-pixel partial sums fit in 32 bits: |Ix|, |Iy| <= 4080 (Scharr of u8, bilinear average),
 // |diff| <= 8160 (u8 << 5), so a 16-lane row (4 pixels per lane) stays below 64 * 8160 * 4080 = 2 130 739 200 < 2^31.
 // The four DPP steps then run on single registers (the adds fold into the DPP instruction) and only the four
@@ -536,12 +539,12 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (pv_[q]) {
-                    Iv[q] = DESCALE(ia[q] * iw00 + ia[q + 1] * iw01 + ib[q] * iw10 + ib[q + 1] * iw11, W_BITS - 5);
-                    Ix[q] = DESCALE(xa[q] * iw00 + xa[q + 1] * iw01 + xb[q] * iw10 + xb[q + 1] * iw11, W_BITS);
-                    Iy[q] = DESCALE(ya[q] * iw00 + ya[q + 1] * iw01 + yb[q] * iw10 + yb[q + 1] * iw11, W_BITS);
-                    pA11 += Ix[q] * Ix[q];
-                    pA12 += Ix[q] * Iy[q];
-                    pA22 += Iy[q] * Iy[q];
+                    Iv[q] = DESCALE(__mul24(ia[q], iw00) + __mul24(ia[q + 1], iw01) + __mul24(ib[q], iw10) + __mul24(ib[q + 1], iw11), W_BITS - 5);
+                    Ix[q] = DESCALE(__mul24(xa[q], iw00) + __mul24(xa[q + 1], iw01) + __mul24(xb[q], iw10) + __mul24(xb[q + 1], iw11), W_BITS);
+                    Iy[q] = DESCALE(__mul24(ya[q], iw00) + __mul24(ya[q + 1], iw01) + __mul24(yb[q], iw10) + __mul24(yb[q + 1], iw11), W_BITS);
+                    pA11 += __mul24(Ix[q], Ix[q]);
+                    pA12 += __mul24(Ix[q], Iy[q]);
+                    pA22 += __mul24(Iy[q], Iy[q]);
                 }
         }
         const long long sA11 = wave_sum_rows_i32(pA11), sA12 = wave_sum_rows_i32(pA12), sA22 = wave_sum_rows_i32(pA22);
@@ -584,10 +587,10 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                     if (pv_[q]) {
-                        int jv = DESCALE(ra[q] * iw00 + ra[q + 1] * iw01 + rb[q] * iw10 + rb[q + 1] * iw11, W_BITS - 5);
+                        int jv = DESCALE(__mul24(ra[q], iw00) + __mul24(ra[q + 1], iw01) + __mul24(rb[q], iw10) + __mul24(rb[q + 1], iw11), W_BITS - 5);
                         int diff = jv - Iv[q];
-                        pb1 += diff * Ix[q];
-                        pb2 += diff * Iy[q];
+                        pb1 += __mul24(diff, Ix[q]);
+                        pb2 += __mul24(diff, Iy[q]);
                     }
             }
             const long long sb1 = wave_sum_rows_i32(pb1), sb2 = wave_sum_rows_i32(pb2);
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(64) void klt_kernel(const uint8_t *__restrict__ pre
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                     if (pv_[q]) {
-                        int jv = DESCALE(ra[q] * iw00 + ra[q + 1] * iw01 + rb[q] * iw10 + rb[q + 1] * iw11, W_BITS - 5);
+                        int jv = DESCALE(__mul24(ra[q], iw00) + __mul24(ra[q + 1], iw01) + __mul24(rb[q], iw10) + __mul24(rb[q + 1], iw11), W_BITS - 5);
                         int diff = jv - Iv[q];
                         pe += diff < 0 ? -diff : diff;
                     }
