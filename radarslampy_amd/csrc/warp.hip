@@ -224,7 +224,7 @@ __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t
         for (int cb = 0; cb < bw; cb += 64) {
             const int c = min(cb + c4, bp - 4);           // clamped lanes rewrite the last column group
             const int x0 = mnx + c;                       // first range bin of this lane's dword
-            const uint8_t *srow = sp + ((int64_t)r * row_stride + x0);
+            const uint8_t *srow = sp + (__mul24(r, (int)row_stride) + x0);       // rows * stride < 2^31 (launcher requirement)
             float *drow = bq + (k * bp + c);
             uint32_t raw[U];
 #pragma unroll
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             else { box_fill<1>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 1; }
         }
         __syncthreads();
+        uint8_t *dq = dst + (int64_t)lb * u8_lane_stride;          // this thread's dword in scan lb, advanced per scan
         for (int q = 0; q < nq; q++) {
             const float *bx = box + q * elems;
             f32x2 ta[4], tb[4];
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
             const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
             const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));
-            if (sok) *reinterpret_cast<uint32_t *>(dst + (int64_t)(lb + q) * u8_lane_stride) = o;
+            if (sok) *reinterpret_cast<uint32_t *>(dq) = o;
+            dq += u8_lane_stride;
         }
         __syncthreads();
     }
