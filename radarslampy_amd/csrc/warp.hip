@@ -398,9 +398,9 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
                 const f32x2 pa = ta[j] * wa[j], pb = tb[j] * wb[j];
                 vq[j] = __fadd_rn(__fadd_rn(__fadd_rn(pa.x, pa.y), pb.x), pb.y);
             }
-            const f32x2 q01 = f32x2{vq[0], vq[1]} * 255.f, q23 = f32x2{vq[2], vq[3]} * 255.f;
-            const uint32_t pk = (uint32_t)(int)q01.x | ((uint32_t)(int)q01.y << 8) | ((uint32_t)(int)q23.x << 16) |
-                                ((uint32_t)(int)q23.y << 24);
+            // (scalar multiplies here: a packed one makes the compiler pack the three adds above as well, at the
+            // price of a dozen register moves)
+            const uint32_t pk = quant_u8(vq[0]) | (quant_u8(vq[1]) << 8) | (quant_u8(vq[2]) << 16) | (quant_u8(vq[3]) << 24);
             const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
             const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
             const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));
