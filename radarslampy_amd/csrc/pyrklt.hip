@@ -6,16 +6,19 @@
 // what is (un)pinned: oracle/c/warp_klt.c.  Integer window sums are exact (int64), every
 // float operation is an explicit round-to-nearest intrinsic => bit-identical to the oracle.
 //
-// pyr_down: 256-thread block -> 64x16 output tile; the (131 x 35) u8 input tile is staged
-//   in LDS with REFLECT_101 addressing, filtered horizontally into LDS (u16), then
-//   vertically; one coalesced u8 store per output.  Reads each level once, writes once.
+// pyr_down: the live shapes stream whole rows - pyr_down_rows_kernel (2024 -> 1012) and
+//   pyr_down2_rows_kernel (1012 -> 506 -> 253 in one pass), see the comments at those kernels;
+//   other shapes use the tiled kernel: 256-thread block -> 64x16 output tile, the (131 x 35) u8
+//   input tile staged in LDS with REFLECT_101 addressing, filtered horizontally into LDS (u16),
+//   then vertically.
 // klt: ONE WAVEFRONT PER FEATURE (64-thread workgroup), all 4 levels in one launch.  Per
 //   level the 18x18 neighbourhood of the previous image is staged in LDS, Scharr
 //   derivatives are formed on the fly (never materialised in HBM: saves 2 x int16 x 4.1 MP
 //   per scan), the 15x15 patch (I, Ix, Iy) lives in registers (4 samples per lane), the
 //   2x2 normal matrix and the per-iteration mismatch vector are wave-wide integer
-//   reductions (DPP/shuffle butterflies), and the 16x16 window of the next image is
-//   re-staged per iteration (L2-resident).  Control flow is wave-uniform.
+//   reductions (32-bit DPP sums per 16-lane row, 64-bit scalar sum of the four rows), and a
+//   32x32 neighbourhood of the next image is cached in LDS per level (reloaded only when the
+//   window leaves it).  Control flow is wave-uniform.
 #include "roam_internal.h"
 
 __device__ __forceinline__ int reflect101(int p, int len)

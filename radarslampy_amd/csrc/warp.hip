@@ -179,17 +179,16 @@ hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
 #define WG_TH 16          // tile height
 #define WG_BOX_ELEMS 4096     // polar samples staged per pass, already decoded to float32 (16 KB)
 #ifndef WG_FILL_U
-#define WG_FILL_U 4
+#define WG_FILL_U 4       // scans whose box rows are loaded before the first load is consumed
 #endif
-//          // independent row loads in flight per wavefront during the fill
 // 256-thread block = 64 x 16 pixel tile; wave w owns rows 4w..4w+3, lane = x offset.
 // The polar footprint of a tile is a small box (range span x azimuth span; median 310 samples,
-// 52 x 7): it is staged in LDS with coalesced row loads (one wavefront per polar row, up to 64
-// consecutive bytes per load) and the 4 bilinear taps per pixel become LDS reads - the PMC
+// 52 x 7): it is staged in LDS with coalesced row loads (16 lanes per polar row, one misaligned
+// dword per lane, four rows per load instruction) and the 4 bilinear taps per pixel become LDS reads - the PMC
 // profile of the direct-gather version showed 28 L1 accesses per wave-level load and the texture
 // addresser 63 % busy.  Because the box is small, the boxes of SEVERAL scans of the batch
-// (WG_BOX_ELEMS / box size, up to WG_LB) are staged in one pass: the fill issues WG_FILL_U
-// independent row loads per wavefront before the first one is consumed, and a pass costs two
+// (WG_BOX_ELEMS / box size, up to WG_LB) are staged in one pass: the fill issues the loads of
+// WG_FILL_U scans per wavefront before the first one is consumed, and a pass costs two
 // barriers whatever the number of scans it covers.  Tiles whose footprint does not fit (next to
 // the image centre, or straddling the 0/2pi seam) fall back to direct L1/L2 gathers; tiles
 // beyond the maximum range write zeros.  A thread's 4 results (4 rows of one column) are
