@@ -203,7 +203,7 @@ def main():
         # whole-path view: SURVEY 8d B_min = 13.07 MB per steady pair
         path_gbs = 13.07e6 * (value / world) / 1e9
         cpu = None
-        if args.cpu_pairs > 0:
+        if args.cpu_pairs > 0 and world == 1:          # the CPU leg is timed on rank 0 of a single-GPU run only
             import oracle
             recs, poses, feat = seqs[0]
             P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=not args.no_md)
