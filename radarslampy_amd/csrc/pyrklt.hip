@@ -209,6 +209,99 @@ __global__ __launch_bounds__(256) void pyr_down_rows_kernel(const uint8_t *__res
     }
 }
 
+// ---- barrier-free streaming variant for the widest level (2024 -> 1012): ONE WAVEFRONT per band of output rows.
+// A lane owns 8 consecutive pixel dwords (32 pixels) of every input row: two 16-byte loads; the horizontal 5-tap
+// needs the neighbouring lanes' edge dwords only (DPP wave shifts), the REFLECT_101 pads are synthesised in the
+// edge lanes; the five most recent horizontally filtered rows live in REGISTERS (5 x 8 packed u16 pairs per lane,
+// the row loop is unrolled by ten so that every ring index is static), and an output row leaves as one 16-byte
+// store per lane.  No LDS, no barriers; two input rows are prefetched ahead of the one being filtered.
+#define PW_DPL 8              // pixel dwords per lane -> rows up to 64 * 8 * 4 = 2048 pixels
+#define PW_CH 32              // output rows per wavefront
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct PwRow { uint32_t d[PW_DPL]; };
+
+__device__ __forceinline__ void pw_load(const uint8_t *__restrict__ s, int w, int h, int wq, int sy, int b0, PwRow &r)
+{
+    const uint32_t *rp = reinterpret_cast<const uint32_t *>(s + (int64_t)sy * w) + b0;
+    if (sy < h - 1) {                                    // reading past the row end stays inside the image
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4 *>(rp), c = *reinterpret_cast<const u32x4_a4 *>(rp + 4);
+        r.d[0] = a.x; r.d[1] = a.y; r.d[2] = a.z; r.d[3] = a.w; r.d[4] = c.x; r.d[5] = c.y; r.d[6] = c.z; r.d[7] = c.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < PW_DPL; j++) r.d[j] = (b0 + j < wq) ? rp[j] : 0u;
+    }
+}
+
+// horizontal 5-tap of one row held in registers -> PW_DPL packed output pairs
+__device__ __forceinline__ void pw_hfilter(const PwRow &r, int lane, int jstar, uint32_t (&out)[PW_DPL])
+{
+    uint32_t D[PW_DPL + 2];
+    D[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.d[PW_DPL - 1], 0x138, 0xf, 0xf, false);   // lane - 1
+    D[PW_DPL + 1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r.d[0], 0x130, 0xf, 0xf, false);   // lane + 1
+#pragma unroll
+    for (int j = 0; j < PW_DPL; j++) D[1 + j] = r.d[j];
+    if (lane == 0) D[0] = (((r.d[0] >> 16) & 255u) << 16) | (((r.d[0] >> 8) & 255u) << 24);          // px[-2] = px[2], px[-1] = px[1]
+#pragma unroll
+    for (int j = 0; j < PW_DPL; j++)                                                                 // px[w] = px[w-2], px[w+1] = px[w-3]
+        if (j == jstar) D[2 + j] = ((D[1 + j] >> 16) & 255u) | (((D[1 + j] >> 8) & 255u) << 8);
+#pragma unroll
+    for (int j = 0; j < PW_DPL; j++) out[j] = pyr_hpair(D[j], D[1 + j], D[2 + j]);
+}
+
+__global__ __launch_bounds__(256) void pyr_down_wave_kernel(const uint8_t *__restrict__ src, int64_t src_lane_stride,
+                                                            int w, int h, uint8_t *__restrict__ dst,
+                                                            int64_t dst_lane_stride, int dw, int dh, int bands)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int band = blockIdx.x * 4 + wv;
+    if (band >= bands) return;
+    const int b = blockIdx.y;
+    const int oy0 = band * PW_CH;
+    const int nout = min(PW_CH, dh - oy0);
+    const int nin = 2 * nout + 3;
+    const uint8_t *s = src + (int64_t)b * src_lane_stride;
+    uint8_t *d = dst + (int64_t)b * dst_lane_stride;
+    const int wq = w >> 2, npair = dw >> 1;
+    const int b0 = lane * PW_DPL;
+    const int jstar = wq - 1 - b0;                       // local index of the last pixel dword of the row (if in this lane)
+    uint32_t R[5][PW_DPL];
+    PwRow pre[2];
+    pw_load(s, w, h, wq, reflect101(2 * oy0 - 2, h), b0, pre[0]);
+    if (nin > 1) pw_load(s, w, h, wq, reflect101(2 * oy0 - 1, h), b0, pre[1]);
+
+#define PW_STEP(K)                                                                                              \
+    if (i0 + (K) < nin) {                                                                                       \
+        const int i = i0 + (K);                                                                                 \
+        pw_hfilter(pre[(K) & 1], lane, jstar, R[(K) % 5]);                                                      \
+        if (i + 2 < nin) pw_load(s, w, h, wq, reflect101(2 * oy0 - 2 + i + 2, h), b0, pre[(K) & 1]);            \
+        if (i >= 4 && !((K) & 1)) {                                                                             \
+            uint32_t o[PW_DPL / 2];                                                                             \
+            _Pragma("unroll") for (int m = 0; m < PW_DPL / 2; m++) {                                            \
+                const uint32_t sa = (R[((K) + 1) % 5][2 * m] + R[(K) % 5][2 * m]) + 4u * (R[((K) + 2) % 5][2 * m] + R[((K) + 4) % 5][2 * m]) + \
+                                    6u * R[((K) + 3) % 5][2 * m] + 0x00800080u;                                 \
+                const uint32_t sb = (R[((K) + 1) % 5][2 * m + 1] + R[(K) % 5][2 * m + 1]) +                      \
+                                    4u * (R[((K) + 2) % 5][2 * m + 1] + R[((K) + 4) % 5][2 * m + 1]) + 6u * R[((K) + 3) % 5][2 * m + 1] + 0x00800080u; \
+                o[m] = __builtin_amdgcn_perm(sb, sa, 0x07050301u);                                              \
+            }                                                                                                   \
+            uint8_t *orow = d + (int64_t)(oy0 + ((i - 4) >> 1)) * dw + 2 * b0;                                  \
+            if (b0 + PW_DPL <= npair) *reinterpret_cast<u32x4_a4 *>(orow) = u32x4_a4{o[0], o[1], o[2], o[3]};   \
+            else {                                                                                              \
+                _Pragma("unroll") for (int m = 0; m < PW_DPL / 2; m++)                                          \
+                    if (b0 + 2 * m + 1 < npair) reinterpret_cast<uint32_t *>(orow)[m] = o[m];                   \
+                    else if (b0 + 2 * m < npair) reinterpret_cast<uint16_t *>(orow)[2 * m] = (uint16_t)o[m];    \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // ring slot of input row i is i % 5; the loop advances ten rows so that K % 5 == i % 5 and K & 1 == i & 1:
+    // row i - 4 is in slot (K + 1) % 5, i - 3 in (K + 2) % 5, i - 2 in (K + 3) % 5, i - 1 in (K + 4) % 5
+    for (int i0 = 0; i0 < nin; i0 += 10) {
+        PW_STEP(0) PW_STEP(1) PW_STEP(2) PW_STEP(3) PW_STEP(4) PW_STEP(5) PW_STEP(6) PW_STEP(7) PW_STEP(8) PW_STEP(9)
+    }
+#undef PW_STEP
+}
+
 // ---- two levels in one pass (1012 -> 506 -> 253): the 506-wide level is neither dword aligned nor large
 // enough to stream well on its own (the tiled kernel above reaches 0.8 TB/s on it).  A block produces PF_CC
 // rows of the SECOND output level: it streams the input rows exactly like pyr_down_rows_kernel to make the
@@ -314,6 +407,14 @@ hipError_t launch_pyr_down(hipStream_t st, const uint8_t *src, int64_t src_lane_
     const bool rows_ok = ((w & 3) == 0) && w >= 16 && w <= PR_MAXW && ((dw & 1) == 0) && ((src_lane_stride & 3) == 0) &&
                          ((dst_lane_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(dst) & 1) == 0) && h >= 4;
+    const bool wave_ok = rows_ok && ((w & 3) == 0) && (w >> 2) > 32 * PW_DPL && (w >> 2) <= 64 * PW_DPL && ((dw & 3) == 0) && h >= 8 &&
+                         ((dst_lane_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 3) == 0);
+    if (wave_ok) {
+        const int bands = (dh + PW_CH - 1) / PW_CH;
+        hipLaunchKernelGGL(pyr_down_wave_kernel, dim3((bands + 3) / 4, B), dim3(256), 0, st, src, src_lane_stride, w, h, dst,
+                           dst_lane_stride, dw, dh, bands);
+        return hipGetLastError();
+    }
     if (rows_ok) {
         dim3 grid((dh + PR_CH - 1) / PR_CH, B);
         hipLaunchKernelGGL(pyr_down_rows_kernel, grid, dim3(256), 0, st, src, src_lane_stride, w, h, dst, dst_lane_stride, dw, dh);
