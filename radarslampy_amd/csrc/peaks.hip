@@ -261,7 +261,10 @@ __global__ __launch_bounds__(64 * PKW_WAVES) void peaks_rows_u8_wave_kernel(Peak
                        (int64_t)r * src.row_stride + src.payload_off;
     const int i0 = lane * 32;
     uint32_t w[8];
-    if (i0 + 31 < cols) {
+    // bins past `cols` never enter a mask (vm below) and are never read back from the LDS copy, so a lane may load
+    // its 32 bytes whenever they lie inside the record row - for the Oxford layout (3768 payload bytes) that is every
+    // lane, including the one that straddles the clip at 2025: no divergent byte-wise tail
+    if (i0 + 32 <= (int)src.row_stride - src.payload_off) {
         const u32x4_a1 a = *reinterpret_cast<const u32x4_a1 *>(p + i0), c = *reinterpret_cast<const u32x4_a1 *>(p + i0 + 16);
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y; w[6] = c.z; w[7] = c.w;
     } else {
