@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64 * PKW_WAVES) void peaks_rows_u8_wave_kernel(Peak
     __shared__ __align__(16) uint8_t pc_s[PKW_WAVES][PKF_MAXC / 2];
     __shared__ __align__(16) uint16_t pm_s[PKW_WAVES][PKF_MAXC / 2];
     __shared__ float ls_s[PKW_WAVES][16];
+    __shared__ float lut_s[PKW_WAVES][256];                // k -> (float)k / 255.f: the sums decode ~3 values per candidate
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y, r = blockIdx.x * PKW_WAVES + wv;
@@ -256,6 +257,9 @@ __global__ __launch_bounds__(64 * PKW_WAVES) void peaks_rows_u8_wave_kernel(Peak
     uint8_t *xb = xb_s[wv], *pc = pc_s[wv];
     uint16_t *pm = pm_s[wv];
     float *ls = ls_s[wv];
+    float *lut = lut_s[wv];
+#pragma unroll
+    for (int q = 0; q < 4; q++) lut[lane * 4 + q] = code_to_f32_pk((uint32_t)(lane * 4 + q));
     const int64_t lane_sel = src.lane_index ? (int64_t)src.lane_index[b] : (int64_t)b;
     const uint8_t *p = reinterpret_cast<const uint8_t *>(src.base) + lane_sel * src.lane_stride +
                        (int64_t)r * src.row_stride + src.payload_off;
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(64 * PKW_WAVES) void peaks_rows_u8_wave_kernel(Peak
         return tot;
     };
     const float fM = (float)M;
-    const float mean = __fdiv_rn(np_sum([&](int k) { return code_to_f32_pk(pc[k]); }), fM);
-    const float var = __fdiv_rn(np_sum([&](int k) { const float d = __fsub_rn(code_to_f32_pk(pc[k]), mean); return __fmul_rn(d, d); }), fM);
+    const float mean = __fdiv_rn(np_sum([&](int k) { return lut[pc[k]]; }), fM);
+    const float var = __fdiv_rn(np_sum([&](int k) { const float d = __fsub_rn(lut[pc[k]], mean); return __fmul_rn(d, d); }), fM);
     const float thr = __fadd_rn(mean, rn_sqrtf(var));
     // threshold + ordered compaction: 16 consecutive candidates per lane (M <= 1024)
     const int k0 = lane * 16;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(64 * PKW_WAVES) void peaks_rows_u8_wave_kernel(Peak
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const uint32_t c = (cws[q >> 2] >> (8 * (q & 3))) & 255u;
-        keep |= (uint32_t)((k0 + q < M) && (code_to_f32_pk(c) >= thr)) << q;
+        keep |= (uint32_t)((k0 + q < M) && (lut[c] >= thr)) << q;
     }
     int total;
     int p2 = wave_excl_scan(__popc(keep), lane, &total);
