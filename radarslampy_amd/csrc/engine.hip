@@ -1,16 +1,16 @@
 // Batched, device-resident scan-pair engine.
 //
 // B independent sequences ("lanes") live in HBM: the raw Oxford records (pool), a ring of
-// three u8 pyramids per lane (previous / current / being filled), the tracked feature set, the
-// keyframe state (+ optionally every past keyframe, 8f-f1) and the poses.  One
-// roam_engine_step() advances EVERY lane by one scan pair with ~15 kernel launches and no host
-// round trip, in two pipelined stages:
-//   front end (own stream; depends only on the raw scan):  ingest+peaks -> warp+quantise -> pyramid
-//   back end:  KLT -> (status & err<10) compaction -> consistency graph -> max clique ->
-//              inlier compaction + keyframe pruning + p_w / p_jt -> Kabsch -> initial transform ->
-//              motion-distortion LM -> pose / keyframe bookkeeping
-// so that when steps are enqueued back to back the front end of step N+1 overlaps the
-// (latency-bound) back end of step N.
+// four u8 pyramids per lane (previous / current / in the pyramid stage / being warped), the
+// tracked feature set, the keyframe state (+ optionally every past keyframe, 8f-f1) and the
+// poses.  One roam_engine_step() advances EVERY lane by one scan pair with ~15 kernel launches
+// and no host round trip, in three pipelined stages on three streams:
+//   A (depends only on the raw scan; issue-bound):  ingest+peaks -> warp+quantise
+//   B (HBM-bound):                                  pyramid
+//   C: KLT -> (status & err<10) compaction -> consistency graph -> max clique ->
+//      inlier compaction + keyframe pruning + p_w / p_jt -> Kabsch -> initial transform ->
+//      motion-distortion LM (latency-bound) -> pose / keyframe bookkeeping
+// so that when steps are enqueued back to back A(N+2), B(N+1) and C(N) share the GPU.
 // It restates the body of RawROAMSystem.run's loop (reference RawROAMSystem.py:162-298)
 // without the plotting, Tracker.track (Tracker.py:35-106) and the Keyframe bookkeeping
 // (Mapping.py:37-66,97-125,149-174).  Scan pairs of different lanes are independent, so the
@@ -38,15 +38,15 @@ struct Engine {
     PyrDesc pd;
     size_t rec_bytes = 0;
     uint8_t *pool = nullptr;
-    uint8_t *pyr[3] = {nullptr, nullptr, nullptr};   // ring: previous / current / the one the front end of the next step fills
+    uint8_t *pyr[4] = {nullptr, nullptr, nullptr, nullptr};   // ring: previous / current / in the pyramid stage / being warped
     uint32_t *warp_map = nullptr;       // W x W sampling map (geometry only)
     int cur = 0;                        // pyr[cur] = previous image pyramids
     uint16_t *row_stage = nullptr;
     int32_t *row_count = nullptr;
-    int32_t *peaks_out[2] = {nullptr, nullptr}, *peaks_n[2] = {nullptr, nullptr};   // double-buffered by step parity
-    int32_t *scan_idx[2] = {nullptr, nullptr};
-    int32_t *scan_host = nullptr;       // pinned staging of the scan indices (2 x B)
-    int pk = 0;                         // parity of the latest step (valid peak / scan-index buffers)
+    int32_t *peaks_out[3] = {nullptr, nullptr, nullptr}, *peaks_n[3] = {nullptr, nullptr, nullptr};   // ring of 3 (stage A runs 2 steps ahead of g4)
+    int32_t *scan_idx[3] = {nullptr, nullptr, nullptr};
+    int32_t *scan_host = nullptr;       // pinned staging of the scan indices (3 x B)
+    int pk = 0;                         // ring slot of the latest step (valid peak / scan-index buffers)
     int64_t nstep = 0;
     float *feat = nullptr;              // B x KS x 2
     int32_t *feat_n = nullptr;
@@ -75,11 +75,12 @@ struct Engine {
     roam_lane_result *results = nullptr;
     hipEvent_t ev[ST_COUNT + 1];
     hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
-    hipEvent_t ev_klt[2], ev_g4[2];                // back-end milestones the front end of step N+2 waits for
+    hipEvent_t ev_klt[4], ev_g4[4];                // back-end milestones stage A of step N+3 waits for
+    hipEvent_t ev_warp;                            // end of stage A (stage B waits for it)
     // per-step boundaries of the three front-end kernels (before peaks | peaks/warp | warp/pyramid | after pyramid),
     // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
     // region without synchronising inside it (roam_engine_kernel_avg)
-    hipEvent_t tr_ev[64][4];
+    hipEvent_t tr_ev[64][5];
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
@@ -378,10 +379,11 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     for (void *p : e->allocs) hipFree(p);
     if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
-                    for (int i = 0; i < 2; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } }
+                    for (int i = 0; i < 4; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } hipEventDestroy(e->ev_warp); }
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
+    hipStreamSynchronize(ctx->stream4);
     delete e;
     ctx->engine = nullptr;
     return ROAM_OK;
@@ -413,15 +415,16 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->pyr[0], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[1], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[2], (size_t)e->pd.lane_stride * B);
+    ok = ok && dalloc(ctx, e, &e->pyr[3], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->warp_map, (size_t)e->W * e->W);
     ok = ok && dalloc(ctx, e, &e->row_stage, (size_t)B * cfg->rows * e->stage_cap);
     ok = ok && dalloc(ctx, e, &e->row_count, (size_t)B * cfg->rows);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         ok = ok && dalloc(ctx, e, &e->peaks_out[i], (size_t)B * cfg->peaks_cap * 2);
         ok = ok && dalloc(ctx, e, &e->peaks_n[i], (size_t)B);
         ok = ok && dalloc(ctx, e, &e->scan_idx[i], (size_t)B);
     }
-    if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->scan_host), sizeof(int32_t) * 2 * (size_t)B, hipHostMallocDefault) != hipSuccess) {
+    if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->scan_host), sizeof(int32_t) * 3 * (size_t)B, hipHostMallocDefault) != hipSuccess) {
         ROAM_SET_ERR(ctx, "engine: hipHostMalloc failed"); ok = false;
     }
     ok = ok && dalloc(ctx, e, &e->feat, (size_t)B * KS * 2);
@@ -464,10 +467,13 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     }
     if (hipEventCreate(&e->ev_join) != hipSuccess ||
         hipEventCreate(&e->ev_pk0) != hipSuccess || hipEventCreate(&e->ev_pk1) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_klt[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_klt[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_g4[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_g4[1], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_warp, hipEventDisableTiming) != hipSuccess) {
         ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
+    for (int i = 0; i < 4; i++)
+        if (hipEventCreateWithFlags(&e->ev_klt[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_g4[i], hipEventDisableTiming) != hipSuccess) {
+            ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
+        }
     e->ev_ok = true;
     for (auto &row : e->tr_ev)
         for (auto &ev : row)
@@ -660,43 +666,48 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     const roam_engine_cfg &c = e->cfg;
     const int nw = KS / 64;
     const int KM = e->kmax();          // host-known bound: feature counts only shrink between (re)seeds
-    // Two-stage pipeline across steps.  FRONT END (peaks, warp, pyramid) depends only on the raw scan: it runs
-    // on its own stream and may start while the BACK END (KLT ... LM, g4) of the previous step is still busy -
-    // that back end is latency-bound (the LM solve holds registers, not issue slots).  Three pyramid buffers
-    // (previous / current / being filled) and parity-indexed peak and scan-index buffers keep the two apart:
-    //   front(N) waits for KLT(N-2)  - the pyramid it overwrites was that tracker's "previous" image
-    //   front(N) waits for g4(N-2)   - peak counts / scan indices of the same parity are read by that kernel
-    //   KLT(N)   waits for front(N)
-    hipStream_t sf = ctx->stream2;
-    const int pb = (int)(e->nstep & 1);
-    uint8_t *prev = e->pyr[e->cur], *next = e->pyr[(e->cur + 1) % 3];
-    HIP_TRY(ctx, hipStreamWaitEvent(sf, e->ev_klt[pb], 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(sf, e->ev_g4[pb], 0));
+    // Three-stage pipeline across steps:
+    //   stage A (stream2): polar peaks + warp          - depend only on the raw scan; issue-bound (VALU / LDS)
+    //   stage B (stream4): pyramid of the warped image - HBM-bound, little arithmetic
+    //   stage C (stream):  KLT ... LM, g4              - needs stage B of its own step and stage C of the previous one
+    // When steps are enqueued back to back, A(N+2), B(N+1) and C(N) run concurrently: the HBM-bound pyramid and the
+    // latency-bound LM solve fill the gaps of the issue-bound kernels.  Four pyramid buffers (previous / current /
+    // in stage B / in stage A) and three peak / scan-index buffers keep the stages apart:
+    //   A(N) waits for KLT(N-3)  - the pyramid it overwrites was that tracker's "previous" image
+    //   A(N) waits for g4(N-3)   - that kernel reads the peak counts / scan indices of the same ring slot
+    //   B(N) waits for A(N), KLT(N) waits for B(N)
+    hipStream_t sA = ctx->stream2, sB = ctx->stream4;
+    const int pb = (int)(e->nstep % 3);                 // ring slot of the peak / scan-index buffers
+    const int k4 = (int)(e->nstep & 3), w4 = (int)((e->nstep + 1) & 3);   // event slot of this step / of step N-3
+    uint8_t *prev = e->pyr[e->cur], *next = e->pyr[(e->cur + 1) & 3];
+    HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_klt[w4], 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_g4[w4], 0));
     // (lane initialisation, retracks and synchronous uploads finish on the host before a step is enqueued)
-    if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(sf, ctx->ev_up, 0)); e->uploads_pending = false; }
+    if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(sA, ctx->ev_up, 0)); e->uploads_pending = false; }
     int32_t *hs = e->scan_host + (size_t)pb * B;
-    if (e->nstep >= 2) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[pb]));   // the staging slot's last copy has long been consumed
+    if (e->nstep >= 3) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[w4]));   // the staging slot's last copy has long been consumed
     for (int b = 0; b < B; b++) hs[b] = scan_idx[b];
-    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, sf));
+    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, sA));
     hipEvent_t *tr = e->tr_ev[e->nstep & 63];
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sf));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sf));
-    HIP_TRY(ctx, hipEventRecord(tr[0], sf));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sA));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sA));
+    HIP_TRY(ctx, hipEventRecord(tr[0], sA));
     PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[pb]};
-    HIP_TRY(ctx, launch_peaks(sf, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sf));
-    HIP_TRY(ctx, hipEventRecord(tr[1], sf));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_WARP], sf));
-    HIP_TRY(ctx, launch_warp_gather(sf, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride));
-    HIP_TRY(ctx, hipEventRecord(tr[2], sf));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PYR], sf));
-    HIP_TRY(ctx, launch_build_pyramid(sf, next, e->pd, B));
-    HIP_TRY(ctx, hipEventRecord(tr[3], sf));
-    HIP_TRY(ctx, hipEventRecord(e->ev_join, sf));                         // end of the front end
+    HIP_TRY(ctx, launch_peaks(sA, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sA));
+    HIP_TRY(ctx, hipEventRecord(tr[1], sA));
+    HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride));
+    HIP_TRY(ctx, hipEventRecord(tr[2], sA));
+    HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
+    HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
+    HIP_TRY(ctx, hipEventRecord(tr[3], sB));
+    HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B));
+    HIP_TRY(ctx, hipEventRecord(tr[4], sB));
+    HIP_TRY(ctx, hipEventRecord(e->ev_join, sB));                         // end of stage B
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
     HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KM, KS, B, e->klt_next, e->klt_status, e->klt_err));
-    HIP_TRY(ctx, hipEventRecord(e->ev_klt[pb], st));
+    HIP_TRY(ctx, hipEventRecord(e->ev_klt[k4], st));
     hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,
                        e->good_old, e->good_new, e->good_idx, e->good_n);
     HIP_TRY(ctx, hipGetLastError());
@@ -732,8 +743,8 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
                        e->map_cap);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
-    HIP_TRY(ctx, hipEventRecord(e->ev_g4[pb], st));
-    e->cur = (e->cur + 1) % 3;
+    HIP_TRY(ctx, hipEventRecord(e->ev_g4[k4], st));
+    e->cur = (e->cur + 1) & 3;
     e->pk = pb;
     e->nstep++;
     e->stepped = true;
@@ -813,8 +824,10 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;
-        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev_pk0, e->ev_pk1));   // front stream
-        else if (i == ST_PYR) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[ST_PYR], e->ev_join));   // front stream, up to its last kernel
+        hipEvent_t *tl = e->tr_ev[(e->nstep - 1) & 63];                                     // stage A / B boundaries of the last step
+        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[0], tl[1]));
+        else if (i == ST_WARP) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[1], tl[2]));
+        else if (i == ST_PYR) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[3], tl[4]));
         else HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
         ms_out[i] = ms;
         if (names_out) names_out[i] = kStageNames[i];
@@ -837,7 +850,8 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
     double sum = 0;
     for (int64_t i = e->nstep - n; i < e->nstep; i++) {
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->tr_ev[i & 63][k], e->tr_ev[i & 63][k + 1]));
+        const int a0 = k == 2 ? 3 : k;                                          // pyramid: its own stream's pair
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->tr_ev[i & 63][a0], e->tr_ev[i & 63][a0 + 1]));
         sum += ms;
     }
     *avg_ms = (float)(sum / (double)n);
@@ -856,7 +870,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     hipStream_t st = ctx->stream;
     const roam_engine_cfg &c = e->cfg;
     const int B = e->B;
-    uint8_t *next = e->pyr[(e->cur + 1) % 3];       // not the live "previous" pyramid
+    uint8_t *next = e->pyr[(e->cur + 1) & 3];       // not the live "previous" pyramid
     double bytes = 0;
     hipEvent_t a, b;
     HIP_TRY(ctx, hipEventCreate(&a));
@@ -869,7 +883,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             bytes = (double)B * ((double)c.rows * c.clip + (double)e->W * e->W);
         } else if (!strcmp(name, "ingest_peaks")) {
             PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[e->pk]};
-            hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[e->pk ^ 1], c.peaks_cap, e->peaks_n[e->pk ^ 1]);
+            hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[(e->pk + 1) % 3], c.peaks_cap, e->peaks_n[(e->pk + 1) % 3]);
             HIP_TRY(ctx, er);
             bytes = (double)B * ((double)c.rows * c.clip);
         } else if (!strcmp(name, "pyramid")) {

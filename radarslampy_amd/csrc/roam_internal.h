@@ -25,7 +25,8 @@ struct Engine;
 struct roam_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;     // front-end stream: peaks, warp, pyramid (independent of the previous step's tracking chain)
+    hipStream_t stream2 = nullptr;     // stage A stream: peaks + warp (depend only on the raw scan)
+    hipStream_t stream4 = nullptr;     // stage B stream: pyramid of the warped image
     hipStream_t stream3 = nullptr;     // copy stream: asynchronous record uploads from pinned host memory
     hipEvent_t ev_up = nullptr, ev_fence = nullptr;
     char err[512] = {0};
