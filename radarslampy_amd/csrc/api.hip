@@ -27,6 +27,7 @@ int32_t roam_create(int32_t device_id, roam_ctx **out)
     // (KLT ... LM) of the previous step; equal priority measured best once the two stages are pipelined
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
     if (hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream2); hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream5, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream4); hipStreamDestroy(ctx->stream2); hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }
     if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_up, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fence, hipEventDisableTiming) != hipSuccess) {
         delete ctx; return ROAM_E_HIP;
@@ -46,9 +47,11 @@ int32_t roam_destroy(roam_ctx *ctx)
     for (auto &s : ctx->scratch) if (s.p) hipFree(s.p);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
+    hipStreamSynchronize(ctx->stream5);
     hipStreamSynchronize(ctx->stream3);
     hipEventDestroy(ctx->ev_up); hipEventDestroy(ctx->ev_fence);
     hipStreamDestroy(ctx->stream3);
+    hipStreamDestroy(ctx->stream5);
     hipStreamDestroy(ctx->stream4);
     hipStreamDestroy(ctx->stream2);
     hipStreamDestroy(ctx->stream);

@@ -4,9 +4,10 @@
 // four u8 pyramids per lane (previous / current / in the pyramid stage / being warped), the
 // tracked feature set, the keyframe state (+ optionally every past keyframe, 8f-f1) and the
 // poses.  One roam_engine_step() advances EVERY lane by one scan pair with ~15 kernel launches
-// and no host round trip, in three pipelined stages on three streams:
-//   A (depends only on the raw scan; issue-bound):  ingest+peaks -> warp+quantise
-//   B (HBM-bound):                                  pyramid
+// and no host round trip, in three pipelined stages (+ the peak kernel on a stream of its own):
+//   P (depends only on the raw scan; joined before the result record):  ingest+peaks
+//   A (depends only on the raw scan; issue-bound):                      warp+quantise
+//   B (HBM-bound):                                                      pyramid
 //   C: KLT -> (status & err<10) compaction -> consistency graph -> max clique ->
 //      inlier compaction + keyframe pruning + p_w / p_jt -> Kabsch -> initial transform ->
 //      motion-distortion LM (latency-bound) -> pose / keyframe bookkeeping
@@ -77,10 +78,11 @@ struct Engine {
     hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[4], ev_g4[4];                // back-end milestones stage A of step N+3 waits for
     hipEvent_t ev_warp;                            // end of stage A (stage B waits for it)
+    hipEvent_t ev_idx, ev_peaks;                   // scan indices uploaded / peak kernel done
     // per-step boundaries of the three front-end kernels (before peaks | peaks/warp | warp/pyramid | after pyramid),
     // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
     // region without synchronising inside it (roam_engine_kernel_avg)
-    hipEvent_t tr_ev[64][5];
+    hipEvent_t tr_ev[64][6];
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
@@ -379,7 +381,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     for (void *p : e->allocs) hipFree(p);
     if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
-                    for (int i = 0; i < 4; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } hipEventDestroy(e->ev_warp); }
+                    for (int i = 0; i < 4; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } hipEventDestroy(e->ev_warp); hipEventDestroy(e->ev_idx); hipEventDestroy(e->ev_peaks); }
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
@@ -467,7 +469,8 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     }
     if (hipEventCreate(&e->ev_join) != hipSuccess ||
         hipEventCreate(&e->ev_pk0) != hipSuccess || hipEventCreate(&e->ev_pk1) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_warp, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e->ev_warp, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_idx, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_peaks, hipEventDisableTiming) != hipSuccess) {
         ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
     for (int i = 0; i < 4; i++)
@@ -667,7 +670,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     const int nw = KS / 64;
     const int KM = e->kmax();          // host-known bound: feature counts only shrink between (re)seeds
     // Three-stage pipeline across steps:
-    //   stage A (stream2): polar peaks + warp          - depend only on the raw scan; issue-bound (VALU / LDS)
+    //   stage A (stream2): warp (+ polar peaks on stream5) - depend only on the raw scan; issue-bound (VALU / LDS)
     //   stage B (stream4): pyramid of the warped image - HBM-bound, little arithmetic
     //   stage C (stream):  KLT ... LM, g4              - needs stage B of its own step and stage C of the previous one
     // When steps are enqueued back to back, A(N+2), B(N+1) and C(N) run concurrently: the HBM-bound pyramid and the
@@ -689,12 +692,18 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     for (int b = 0; b < B; b++) hs[b] = scan_idx[b];
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, sA));
     hipEvent_t *tr = e->tr_ev[e->nstep & 63];
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sA));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sA));
-    HIP_TRY(ctx, hipEventRecord(tr[0], sA));
+    // the peak kernel gets its own stream: it only needs the scan indices (event ev_idx) and is joined before g4
+    hipStream_t sP = ctx->stream5;
+    HIP_TRY(ctx, hipEventRecord(e->ev_idx, sA));
+    HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_idx, 0));
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sP));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sP));
+    HIP_TRY(ctx, hipEventRecord(tr[0], sP));
     PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[pb]};
-    HIP_TRY(ctx, launch_peaks(sA, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sA));
+    HIP_TRY(ctx, launch_peaks(sP, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
+    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sP));
+    HIP_TRY(ctx, hipEventRecord(tr[5], sP));
+    HIP_TRY(ctx, hipEventRecord(e->ev_peaks, sP));
     HIP_TRY(ctx, hipEventRecord(tr[1], sA));
     HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride));
     HIP_TRY(ctx, hipEventRecord(tr[2], sA));
@@ -737,6 +746,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_peaks, 0));
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
                        e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n[pb],
                        e->cq_flags, e->results, e->scan_idx[pb], e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
@@ -825,7 +835,7 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;
         hipEvent_t *tl = e->tr_ev[(e->nstep - 1) & 63];                                     // stage A / B boundaries of the last step
-        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[0], tl[1]));
+        if (i == ST_PEAKS) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[0], tl[5]));
         else if (i == ST_WARP) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[1], tl[2]));
         else if (i == ST_PYR) HIP_TRY(ctx, hipEventElapsedTime(&ms, tl[3], tl[4]));
         else HIP_TRY(ctx, hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
@@ -850,8 +860,8 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
     double sum = 0;
     for (int64_t i = e->nstep - n; i < e->nstep; i++) {
         float ms = 0;
-        const int a0 = k == 2 ? 3 : k;                                          // pyramid: its own stream's pair
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->tr_ev[i & 63][a0], e->tr_ev[i & 63][a0 + 1]));
+        const int a0 = k == 2 ? 3 : (k == 1 ? 1 : 0), a1 = k == 2 ? 4 : (k == 1 ? 2 : 5);   // peaks and pyramid: their own streams' pairs
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e->tr_ev[i & 63][a0], e->tr_ev[i & 63][a1]));
         sum += ms;
     }
     *avg_ms = (float)(sum / (double)n);

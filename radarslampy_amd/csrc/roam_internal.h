@@ -27,6 +27,7 @@ struct roam_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // stage A stream: peaks + warp (depend only on the raw scan)
     hipStream_t stream4 = nullptr;     // stage B stream: pyramid of the warped image
+    hipStream_t stream5 = nullptr;     // polar peaks (independent of everything but the raw scan)
     hipStream_t stream3 = nullptr;     // copy stream: asynchronous record uploads from pinned host memory
     hipEvent_t ev_up = nullptr, ev_fence = nullptr;
     char err[512] = {0};
