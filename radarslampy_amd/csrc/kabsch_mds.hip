@@ -365,7 +365,11 @@ __device__ void lmpar6(int m, double *a, const int *ipvt, const double *diag, co
 
 #define LM_LDS_BYTES 65536
 
-__global__ __launch_bounds__(LM_TMAX) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
+// 3 wavefronts per SIMD (<= 168 VGPRs, a few values spill): alone the solve is 15 % slower than at 219 VGPRs, but in
+// the pipelined engine it shares every SIMD with the warp / pyramid / tracker of other steps for its whole (latency-
+// bound) duration, and two 219-register wavefronts left room for nothing else (A/B: +1.9 % scan-pairs/s)
+#define LM_WPE 3
+__global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
                                                       double *__restrict__ out6, int32_t *__restrict__ nfev_out,
                                                       int32_t *__restrict__ info_out, double *__restrict__ x0_out,
                                                       double *__restrict__ r0_out, int lds_bytes)
