@@ -185,7 +185,11 @@ int32_t roam_engine_copy_scan(roam_ctx *ctx, int32_t dst_idx, int32_t src_idx);
 int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const float *pts,
                               int32_t K, const double *pose3);
 /* advance every lane by one scan pair: lane i consumes pool scan scan_idx[i] as its current
- * scan.  Asynchronous on the context stream. */
+ * scan.  Asynchronous: the call only enqueues work (scan_idx is copied before it returns).  Steps
+ * enqueued back to back are pipelined on the device - peaks / warp of step N+2, the pyramid of step
+ * N+1 and the tracking + pose solve of step N run concurrently - with results identical to
+ * synchronised execution; roam_engine_results and the other blocking accessors return the state
+ * after the LAST enqueued step.  The host may run at most three steps ahead of the device. */
 int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx);
 /* blocking: fetch the per-lane results of the last step */
 int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
