@@ -9,16 +9,23 @@ Layout
   oracle/__init__.py  ctypes wrappers with the reference's call signatures + the small
                     numpy-only pieces (Kabsch, SE(2) helpers, feature dedupe, Tracker glue)
 
-Parity status (details in DESIGN.md §oracle):
-  PINNED by goldens produced by the reference itself (tests/golden/*.npz):
+Parity status (details in DESIGN.md §4):
+  PINNED by goldens produced by the reference itself (tests/golden/*.npz, make_goldens.py):
       getPointCloudPolarInd, ssc, calculateTransformSVD, rejectOutliers (size always, set when
       the maximum clique is unique), MotionDistortionSolver (error_vector, undistort,
       compute_time_deltas, optimize_library), utils SE(2) helpers, record decode,
       Tracker.track glue, Keyframe glue.
-  PARITY UNPINNED (OpenCV / scikit-image are un-vendored, absent, version-unpinned deps):
-      convertPolarImageToCartesian (cv2.warpPolar), getTrackedPointsKLT
-      (cv2.calcOpticalFlowPyrLK), getBlobsFromCart (skimage blob_doh) — restated from the
-      published algorithms with the reference's parameters; validated by known-answer tests.
+  PINNED by outputs of the reference's own cv2 / scikit-image / SciPy / NumPy stack that the reference
+  repository holds for its 11 real data/tiny scans (tests/golden/tiny_track.npz, make_tiny_track.py;
+  tests/test_oracle_reference_dump.py):
+      convertPolarImageToCartesian (cv2.warpPolar), getTrackedPointsKLT (cv2.calcOpticalFlowPyrLK incl. the
+      pyramid), getBlobsFromCart (skimage blob_doh incl. response order and _prune_blobs' pair order),
+      adaptiveNMS (NumPy 1.22 argsort tie order + ssc): all 257 feature rows of img/dead_reckoning/tiny_10.npz
+      are reproduced (232 bit for bit, 25 within 0.01 px) and 2170 of 2192 ANMS selections drawn in
+      img/blob/tiny/*.jpg (five of the eleven frames without a single difference).  The remainder is traced to
+      +-1 grey-level pixels of the reference's warp: its OpenCV build takes the map radius from IPP's
+      ippsMagnitude_32f rather than a correctly rounded sqrt; every identified pixel sits on a rounding tie of
+      rho*32.  Not reproducible without that binary, and not a property of the algorithm.
 """
 import ctypes as C
 import os
@@ -29,7 +36,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 _LIB = os.path.join(_BUILD, "liboracle.so")
-_SRCS = ["peaks.c", "warp_klt.c", "clique.c", "lm.c", "ssc.c", "doh.c"]
+_SRCS = ["peaks.c", "warp_klt.c", "clique.c", "lm.c", "ssc.c", "doh.c", "prune.c"]
 
 RANGE_RESOLUTION_M = 0.0432          # parseData.py:9
 RANGE_RESOLUTION_CART_M = 0.0864     # parseData.py:13
@@ -358,56 +365,56 @@ def doh_maxima(img, sigma_list, threshold, cap=1 << 18):
     return rcs[:n], val[:n], layers
 
 
-def _overlap2d(b1, b2):
-    import math
-    if b1[2] == b2[2] == 0:
-        return 0.0
-    if b1[2] > b2[2]:
-        ms, r1, r2 = b1[2], 1.0, b2[2] / b1[2]
-    else:
-        ms, r2, r1 = b2[2], 1.0, b1[2] / b2[2]
-    d = math.hypot((b2[0] - b1[0]) / (ms * math.sqrt(2)), (b2[1] - b1[1]) / (ms * math.sqrt(2)))
-    if d > r1 + r2:
-        return 0.0
-    if d <= abs(r1 - r2):
-        return 1.0
-    q1 = min(1.0, max(-1.0, (d * d + r1 * r1 - r2 * r2) / (2 * d * r1)))
-    q2 = min(1.0, max(-1.0, (d * d + r2 * r2 - r1 * r1) / (2 * d * r2)))
-    area = r1 * r1 * math.acos(q1) + r2 * r2 * math.acos(q2) - 0.5 * math.sqrt(abs((-d + r2 + r1) * (d - r2 + r1) * (d + r2 - r1) * (d + r2 + r1)))
-    return area / (math.pi * min(r1, r2) ** 2)
+def ckdtree_pairs(pts, r):
+    """pairs (P,2) int64 in the order scipy.spatial.cKDTree(pts).query_pairs(r) emits them, and the
+    tree's index permutation (restated in oracle/c/prune.c; checked against live scipy in the tests)"""
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+    n = pts.shape[0]
+    out = C.POINTER(C.c_int64)()
+    idx = np.empty(max(n, 1), np.int64)
+    lib().oracle_ckdtree_pairs.restype = C.c_int64
+    m = lib().oracle_ckdtree_pairs(_p(pts, C.c_double), C.c_int64(n), C.c_double(float(r)), C.byref(out), _p(idx, C.c_int64))
+    pairs = np.ctypeslib.as_array(out, shape=(m, 2)).copy() if m else np.empty((0, 2), np.int64)
+    lib().oracle_free(out)
+    return pairs, idx[:n]
+
+
+def pyset_order(pairs):
+    """iteration order (indices into pairs) of the Python set built by adding the (i, j) tuples in order"""
+    pairs = np.ascontiguousarray(pairs, np.int64).reshape(-1, 2)
+    order = np.empty(max(len(pairs), 1), np.int64)
+    lib().oracle_pyset_order.restype = C.c_int64
+    m = lib().oracle_pyset_order(_p(pairs, C.c_int64), C.c_int64(len(pairs)), _p(order, C.c_int64))
+    return order[:m]
+
+
+def prune_blobs(blobs, overlap=0.5):
+    """skimage.feature.blob._prune_blobs in scikit-image's own pair order (cKDTree.query_pairs -> Python set)"""
+    bl = np.ascontiguousarray(blobs, np.float64).copy()
+    lib().oracle_prune_blobs.restype = C.c_int64
+    lib().oracle_prune_blobs(_p(bl, C.c_double), C.c_int64(len(bl)), C.c_double(overlap))
+    return bl[bl[:, 2] > 0]
+
+
+def argsort_numpy122(v):
+    """np.argsort(v) as numpy 1.22.3 (the reference's pin) computes it: npy_aquicksort, unstable"""
+    v = np.ascontiguousarray(v, np.float64)
+    out = np.empty(max(len(v), 1), np.int64)
+    lib().oracle_aquicksort_f64(_p(v, C.c_double), C.c_int64(len(v)), _p(out, C.c_int64))
+    return out[:len(v)]
 
 
 def blob_doh(image, min_sigma=1, max_sigma=30, num_sigma=10, threshold=0.01, overlap=0.5):
-    """skimage.feature.blob_doh restatement (getFeatures.py:47-51): maxima ordered by response,
-    then _prune_blobs with the candidate pairs taken in ascending (i, j) order (brute-force
-    pair search here, independent of the product's k-d tree)."""
+    """skimage.feature.blob_doh restatement (getFeatures.py:47-51): maxima ordered by response
+    (peak_local_max), then _prune_blobs in scikit-image's pair order."""
     sig = np.linspace(min_sigma, max_sigma, num_sigma)
     rcs, val, _ = doh_maxima(image, sig, threshold)
     if len(rcs) == 0:
         return np.empty((0, 3))
-    idx = np.argsort(-val)
+    idx = np.argsort(-val, kind="stable")            # no ties on real images; C (row, col, sigma) order breaks them
     bl = rcs[idx].astype(np.float64)
     bl[:, 2] = sig[rcs[idx][:, 2]]
-    dist = 2 * bl[:, 2].max() * np.sqrt(2)
-    order = np.argsort(bl[:, 0], kind="stable")
-    rows = bl[order, 0]
-    n = len(bl)
-    pairs = []
-    for a in range(n):                                   # sweep over rows: candidates within `dist` rows
-        i = order[a]
-        hi = np.searchsorted(rows, rows[a] + dist, side="right")
-        js = order[a + 1:hi]
-        if len(js):
-            d2 = (bl[js, 0] - bl[i, 0]) ** 2 + (bl[js, 1] - bl[i, 1]) ** 2
-            for j in js[d2 <= dist * dist]:
-                pairs.append((min(i, j), max(i, j)))
-    for i, j in sorted(pairs):
-        if _overlap2d(bl[i], bl[j]) > overlap:
-            if bl[i, 2] > bl[j, 2]:
-                bl[j, 2] = 0
-            else:
-                bl[i, 2] = 0
-    return bl[bl[:, 2] > 0]
+    return prune_blobs(bl, overlap)
 
 
 def getFeatures(img):
@@ -420,7 +427,7 @@ def getFeatures(img):
 def adaptiveNMS(img_shape, blobs, ret_points=200, tolerance=0.1):
     """getFeatures.py:66-72."""
     H, W = img_shape
-    kp = blobs[np.argsort(blobs[:, 2])]
+    kp = blobs[argsort_numpy122(blobs[:, 2])]
     return ssc(kp, ret_points, tolerance, W, H)
 
 

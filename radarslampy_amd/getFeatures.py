@@ -42,16 +42,16 @@ def _blob_overlap(b1, b2):
 
 
 def _prune_blobs(blobs, overlap):
-    """skimage.feature.blob._prune_blobs.  scikit-image walks the candidate pairs in the
-    iteration order of a Python set (not reproducible); here they are walked in ascending
-    (i, j) order of the response-sorted blob array - documented in DESIGN.md."""
+    """skimage.feature.blob._prune_blobs (scikit-image 0.19.2), pair order included: the candidate pairs come out of
+    cKDTree.query_pairs as a Python set and are visited in that set's iteration order - chains of overlapping blobs
+    make the result order dependent (0-3 blobs per real frame), so the same construct is used here.
+    (The engine's device-side retrack restates the same order natively: csrc/blobprune.h.)"""
     from scipy import spatial
     sigma = blobs[:, -1].max()
     distance = 2 * sigma * math.sqrt(blobs.shape[1] - 1)
-    pairs = spatial.cKDTree(blobs[:, :-1]).query_pairs(distance, output_type="ndarray")
+    pairs = np.array(list(spatial.cKDTree(blobs[:, :-1]).query_pairs(distance)))
     if len(pairs) == 0:
         return blobs
-    pairs = pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]
     blobs = blobs.copy()
     for i, j in pairs:
         b1, b2 = blobs[i], blobs[j]
@@ -61,6 +61,79 @@ def _prune_blobs(blobs, overlap):
             else:
                 b1[-1] = 0
     return blobs[blobs[:, -1] > 0]
+
+
+def argsort_numpy122(keys) -> np.ndarray:
+    """np.argsort(keys) with the tie order of the reference's pinned NumPy (1.22.3, requirements.txt:3): its default
+    sort is an introsort (median of three, Hoare partition, insertion sort for runs of <= 17 elements) that is NOT
+    stable, and adaptiveNMS sorts ~400 blobs by a sigma that takes two values (getFeatures.py:69) - the order of
+    the ties decides which blobs SSC keeps.  NumPy >= 2 uses vectorised sorts with a different tie order."""
+    v = [float(x) for x in keys]
+    n = len(v)
+    t = list(range(n))
+    if n < 2:
+        return np.array(t, np.int64)
+    lo, hi, todo, budget = 0, n - 1, [], 2 * (n.bit_length() - 1)
+    while True:
+        if budget < 0:                                   # depth limit: heap sort of the run (never reached for blob counts)
+            t[lo:hi + 1] = _heap_argsort(v, t[lo:hi + 1])
+        else:
+            while hi - lo > 16:
+                mid = lo + ((hi - lo) >> 1)
+                if v[t[mid]] < v[t[lo]]: t[mid], t[lo] = t[lo], t[mid]
+                if v[t[hi]] < v[t[mid]]: t[hi], t[mid] = t[mid], t[hi]
+                if v[t[mid]] < v[t[lo]]: t[mid], t[lo] = t[lo], t[mid]
+                pivot = v[t[mid]]
+                i, j = lo, hi - 1
+                t[mid], t[j] = t[j], t[mid]
+                while True:
+                    i += 1
+                    while v[t[i]] < pivot: i += 1
+                    j -= 1
+                    while pivot < v[t[j]]: j -= 1
+                    if i >= j:
+                        break
+                    t[i], t[j] = t[j], t[i]
+                t[i], t[hi - 1] = t[hi - 1], t[i]
+                budget -= 1
+                if i - lo < hi - i:                      # the larger part waits, the smaller one is sorted first
+                    todo.append((i + 1, hi, budget)); hi = i - 1
+                else:
+                    todo.append((lo, i - 1, budget)); lo = i + 1
+            for i in range(lo + 1, hi + 1):
+                cur, j = t[i], i
+                while j > lo and v[cur] < v[t[j - 1]]:
+                    t[j] = t[j - 1]; j -= 1
+                t[j] = cur
+        if not todo:
+            break
+        lo, hi, budget = todo.pop()
+    return np.array(t, np.int64)
+
+
+def _heap_argsort(v, idx):
+    a = [None] + list(idx)
+    n = len(idx)
+    for l in range(n >> 1, 0, -1):
+        tmp, i, j = a[l], l, l << 1
+        while j <= n:
+            if j < n and v[a[j]] < v[a[j + 1]]: j += 1
+            if v[tmp] < v[a[j]]:
+                a[i] = a[j]; i = j; j += j
+            else:
+                break
+        a[i] = tmp
+    while n > 1:
+        tmp = a[n]; a[n] = a[1]; n -= 1
+        i, j = 1, 2
+        while j <= n:
+            if j < n and v[a[j]] < v[a[j + 1]]: j += 1
+            if v[tmp] < v[a[j]]:
+                a[i] = a[j]; i = j; j += j
+            else:
+                break
+        a[i] = tmp
+    return a[1:]
 
 
 def getBlobsFromCart(cartImage: np.ndarray, min_sigma=1, max_sigma=30, num_sigma=10, threshold=0.01, method="doh",
@@ -80,7 +153,7 @@ def blobs_from_maxima(rcs, val, sigma_list, overlap=0.5):
     """host bookkeeping of blob_doh after the image-scale work: response order, sigma lookup, pruning"""
     if len(rcs) == 0:
         return np.empty((0, 3))
-    idx = np.argsort(-val)                        # peak_local_max: highest response first
+    idx = np.argsort(-val, kind="stable")         # peak_local_max: highest response first
     lm = rcs[idx].astype(np.float64)
     lm[:, -1] = sigma_list[rcs[idx][:, -1]]
     return _prune_blobs(lm, overlap)
@@ -88,7 +161,7 @@ def blobs_from_maxima(rcs, val, sigma_list, overlap=0.5):
 
 def adaptiveNMS(img, blobs, ret_points=200, tolerance=0.1):
     H, W = img.shape
-    keypoints = blobs[np.argsort(blobs[:, 2]), :]
+    keypoints = blobs[argsort_numpy122(blobs[:, 2]), :]
     return ssc(keypoints, ret_points, tolerance, W, H)
 
 
