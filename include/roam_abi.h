@@ -231,6 +231,38 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
 int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms,
                                 double *algo_bytes_per_launch);
 
+/* ---- multi-GPU.  One process per GPU, sequences sharded by rank, no data-path collective.  The only exchange
+ * of the path is handing a keyframe to a global map (reference Mapping.Map.addKeyframe, Mapping.py:118-147; BASELINE
+ * config 5): the owning rank broadcasts the DEVICE-RESIDENT keyframe of one lane with ncclBroadcast (RCCL over xGMI).
+ * RCCL is bound at run time (librccl.so); without it these calls return ROAM_E_STATE.
+ * Rendezvous is the caller's business: rank 0 obtains the id, ships the 128 bytes to the other ranks by any means
+ * (bench.py: a file), then every rank calls roam_comm_init collectively. */
+#define ROAM_COMM_ID_BYTES 128
+int32_t roam_comm_unique_id(uint8_t *id_out /* [ROAM_COMM_ID_BYTES] */);
+int32_t roam_comm_init(roam_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
+int32_t roam_comm_destroy(roam_ctx *ctx);
+/* rank / size as RCCL reports them (ncclCommUserRank / ncclCommCount) */
+int32_t roam_comm_info(roam_ctx *ctx, int32_t *rank, int32_t *world);
+/* blocking in-place all-reduce of n <= 8 doubles, op 0 = max, 1 = sum (max-over-ranks wall time); barrier = sum of ones */
+int32_t roam_comm_allreduce_f64(roam_ctx *ctx, double *inout, int32_t n, int32_t op);
+int32_t roam_comm_barrier(roam_ctx *ctx);
+
+typedef struct roam_keyframe_hdr {
+    double pose[3];           /* keyframe pose [x,y,th]                                   */
+    double velocity[3];       /* velocity the keyframe's points were undistorted with      */
+    int32_t n_features;       /* rows of locals_xy (prunedUndistortedLocals, metres)       */
+    int32_t n_peaks;          /* rows of the polar point cloud [azimuthIdx, rangeIdx]      */
+    int32_t scan;             /* pool scan the keyframe was created on                     */
+    int32_t lane;             /* lane of the root rank it belongs to                       */
+} roam_keyframe_hdr;
+
+/* collective: every rank of the communicator calls it with the same root and lane.  The root packs the LIVE keyframe of
+ * its lane `lane` {pose, velocity, prunedUndistortedLocals, latest polar peaks} on the device, all ranks receive it in a
+ * device buffer (two ncclBroadcast calls: header + features, then the peak list), then copy it to the caller's arrays:
+ * locals_xy (cap_pts, 2) f64, peaks (peaks_cap, 2) i32.  Either array may be NULL (its part is then not copied out). */
+int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyframe_hdr *hdr_out, double *locals_xy,
+                            int32_t cap_pts, int32_t *peaks, int64_t peaks_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,12 @@ class LaneResult(C.Structure):
                 ("lm_info", C.c_int32), ("flags", C.c_int32), ("pad", C.c_int32)]
 
 
+class KeyframeHdr(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("velocity", C.c_double * 3), ("n_features", C.c_int32), ("n_peaks", C.c_int32),
+                ("scan", C.c_int32), ("lane", C.c_int32)]
+
+
+COMM_ID_BYTES = 128
 _P = C.POINTER
 _vp = C.c_void_p
 _SIGS = {
@@ -77,6 +83,13 @@ _SIGS = {
     "roam_engine_map_get": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "roam_engine_stage_times": (C.c_int32, [_vp, _vp, _P(C.c_char_p), C.c_int32, _P(C.c_int32)]),
     "roam_engine_time_kernel": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_float), _P(C.c_double)]),
+    "roam_comm_unique_id": (C.c_int32, [_vp]),
+    "roam_comm_init": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
+    "roam_comm_destroy": (C.c_int32, [_vp]),
+    "roam_comm_info": (C.c_int32, [_vp, _P(C.c_int32), _P(C.c_int32)]),
+    "roam_comm_allreduce_f64": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
+    "roam_comm_barrier": (C.c_int32, [_vp]),
+    "roam_bcast_keyframe": (C.c_int32, [_vp, C.c_int32, C.c_int32, _P(KeyframeHdr), _vp, C.c_int32, _vp, C.c_int64]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 

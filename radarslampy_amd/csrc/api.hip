@@ -42,6 +42,7 @@ int32_t roam_destroy(roam_ctx *ctx)
 {
     if (!ctx) return ROAM_E_ARG;
     hipSetDevice(ctx->device);
+    roam_comm_destroy(ctx);
     roam_engine_destroy(ctx);
     hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->scratch) if (s.p) hipFree(s.p);

@@ -74,6 +74,7 @@ struct Engine {
     double *lm_work = nullptr, *lm_out = nullptr;
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
     roam_lane_result *results = nullptr;
+    uint8_t *kfb = nullptr;                         // 8e: packed keyframe payload (RCCL broadcast buffer)
     hipEvent_t ev[ST_COUNT + 1];
     hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[4], ev_g4[4];                // back-end milestones stage A of step N+3 waits for
@@ -369,6 +370,36 @@ __global__ void lane_kf_reset_kernel(const float *__restrict__ feat, int K, cons
     kf_und[2 * j + 1] = sa * x + ca * y + vel[1] * dT;
 }
 
+// 8e: keyframe payload of one lane for the RCCL broadcast, packed on the device:
+//   [0..63]   roam_keyframe_hdr (pose, velocity, n_features, n_peaks, scan, lane)
+//   [64.. ]   KS x 2 f64 prunedUndistortedLocals
+//   [64 + KS*16 ..]  peaks_cap x 2 i32 polar peaks of the lane's latest scan
+#define KFB_HDR 64
+#define KFB_LOCALS_OFF KFB_HDR
+#define KFB_PEAKS_OFF (KFB_HDR + KS * 16)
+__global__ __launch_bounds__(256) void kf_pack_kernel(uint8_t *__restrict__ buf, int lane, const double *__restrict__ kf_pose,
+                                                      const double *__restrict__ kf_vel, const int32_t *__restrict__ feat_n,
+                                                      const int32_t *__restrict__ kf_scan, const double *__restrict__ kf_und,
+                                                      const int32_t *__restrict__ peaks_n, const int32_t *__restrict__ peaks,
+                                                      int peaks_cap)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    int n = feat_n[lane], P = peaks_n[lane];
+    if (n > KS) n = KS;
+    if (P > peaks_cap) P = peaks_cap;
+    if (t == 0) {
+        roam_keyframe_hdr *h = reinterpret_cast<roam_keyframe_hdr *>(buf);
+        for (int i = 0; i < 3; i++) { h->pose[i] = kf_pose[3 * lane + i]; h->velocity[i] = kf_vel[3 * lane + i]; }
+        h->n_features = n; h->n_peaks = P; h->scan = kf_scan[lane]; h->lane = lane;
+    }
+    double *loc = reinterpret_cast<double *>(buf + KFB_LOCALS_OFF);
+    const double *src = kf_und + (size_t)lane * KS * 2;
+    for (int j = t; j < 2 * n; j += nt) loc[j] = src[j];
+    int32_t *pk = reinterpret_cast<int32_t *>(buf + KFB_PEAKS_OFF);
+    const int32_t *ps = peaks + (size_t)lane * peaks_cap * 2;
+    for (int j = t; j < 2 * P; j += nt) pk[j] = ps[j];
+}
+
 // ------------------------------------------------------------------------------ API
 extern "C" {
 
@@ -656,6 +687,44 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
     HIP_TRY(ctx, hipMemcpyAsync(e->vel + 3 * (size_t)lane, zero, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return set_features_impl(ctx, e, lane, pts, K, pool_idx);
+}
+
+int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyframe_hdr *hdr_out, double *locals_xy,
+                            int32_t cap_pts, int32_t *peaks, int64_t peaks_cap)
+{
+    ENGINE();
+    ARG_CHECK(ctx, hdr_out && lane >= 0 && cap_pts >= 0 && peaks_cap >= 0);
+    static_assert(sizeof(roam_keyframe_hdr) == KFB_HDR, "header layout");
+    const size_t total = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
+    if (!e->kfb && !dalloc(ctx, e, &e->kfb, total)) return ROAM_E_HIP;
+    hipStream_t st = ctx->stream;
+    if (roam_comm_rank(ctx) == root) {
+        ARG_CHECK(ctx, lane < e->B);
+        hipLaunchKernelGGL(kf_pack_kernel, dim3(16), dim3(256), 0, st, e->kfb, lane, e->kf_pose, e->kf_vel, e->feat_n, e->kf_scan,
+                           e->kf_und, e->peaks_n[e->pk], e->peaks_out[e->pk], e->cfg.peaks_cap);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    // header + features (fixed 16.4 KB), then the peak list sized by the header: two latency-bound broadcasts
+    int32_t rc = roam_comm_bcast_bytes(ctx, e->kfb, KFB_PEAKS_OFF, root);
+    if (rc != ROAM_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(hdr_out, e->kfb, sizeof(roam_keyframe_hdr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int n = hdr_out->n_features, P = hdr_out->n_peaks;
+    if (n < 0 || n > KS || P < 0 || P > e->cfg.peaks_cap) { ROAM_SET_ERR(ctx, "bcast_keyframe: corrupt header (n=%d, P=%d)", n, P); return ROAM_E_STATE; }
+    if (P > 0) {
+        rc = roam_comm_bcast_bytes(ctx, e->kfb + KFB_PEAKS_OFF, (size_t)P * 8, root);
+        if (rc != ROAM_OK) return rc;
+    }
+    if (locals_xy) {
+        if (n > cap_pts) { ROAM_SET_ERR(ctx, "bcast_keyframe: %d features, capacity %d", n, cap_pts); return ROAM_E_CAPACITY; }
+        if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(locals_xy, e->kfb + KFB_LOCALS_OFF, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
+    }
+    if (peaks) {
+        if (P > peaks_cap) { ROAM_SET_ERR(ctx, "bcast_keyframe: %d peaks, capacity %lld", P, (long long)peaks_cap); return ROAM_E_CAPACITY; }
+        if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(peaks, e->kfb + KFB_PEAKS_OFF, sizeof(int32_t) * 2 * (size_t)P, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ROAM_OK;
 }
 
 int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)

@@ -21,6 +21,7 @@ struct DevBuf {
 };
 
 struct Engine;
+struct Comm;
 
 struct roam_ctx {
     int device = 0;
@@ -35,6 +36,7 @@ struct roam_ctx {
     DevBuf scratch[24];
     int cu_count = 0;
     Engine *engine = nullptr;
+    Comm *comm = nullptr;              // RCCL communicator (comm.hip), optional
 };
 
 #define ROAM_SET_ERR(ctx, ...) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__)
@@ -147,3 +149,7 @@ hipError_t launch_ssc(hipStream_t st, const double *kp, int B, int num_ret, doub
 int32_t roam_doh_maxima_record_device(roam_ctx *ctx, const uint8_t *rec, int rows, int64_t stride, int payload_off,
                                       int clip, const double *sigmas, int32_t num_sigma, double threshold,
                                       int32_t *out_rcs, double *out_val, int32_t cap, int32_t *n_out);
+
+// comm.hip: in-place byte broadcast of a device buffer on ctx->stream (asynchronous), this rank's index
+int32_t roam_comm_bcast_bytes(roam_ctx *ctx, void *dev_buf, size_t bytes, int root);
+int roam_comm_rank(const roam_ctx *ctx);

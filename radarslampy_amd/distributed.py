@@ -1,10 +1,17 @@
-"""Multi-GPU plumbing: one process per GPU, sequences sharded by rank, no data-path collective.
+"""Multi-GPU plumbing: one process per GPU, sequences sharded by rank, NO data-path collective.
 
-The only exchange the path has is the keyframe broadcast for a global map (BASELINE config 5,
-SURVEY §8e): {pose, velocity, features (K,2) f32, polar peaks (P,2) i32} from the owning rank to
-all ranks - one RCCL broadcast over xGMI (backend "nccl" on ROCm), ~45 KB, latency-bound.
-torch.distributed is used as plumbing only (process group + broadcast); with the gloo backend the
-same code runs on CPU tensors (tests)."""
+The only exchange the path has is handing a keyframe to a global map (reference Mapping.Map.addKeyframe,
+Mapping.py:118-147; BASELINE config 5): `RcclComm.bcast_keyframe` broadcasts the device-resident keyframe of one lane
+of the owning rank with ncclBroadcast (RCCL over xGMI) through the C-ABI (roam_comm_* / roam_bcast_keyframe,
+csrc/comm.hip) - no torch, no host bounce of the payload on the sending side.
+
+Rendezvous (who am I, where is the ncclUniqueId) is a directory on the node's local file system: rank 0 writes the
+128-byte id, the others read it.  `FileComm` offers the same interface on files only; it exists for `bench.py
+--dry-engine`, the CPU test of the launcher, and is never used on a GPU run."""
+import json
+import os
+import time
+
 import numpy as np
 
 
@@ -13,40 +20,149 @@ def shard_sequences(n_sequences: int, rank: int, world: int):
     return [s for s in range(n_sequences) if s % world == rank]
 
 
-def _device(dist):
-    import torch
-    if dist.get_backend() == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
+def rank_env(env=os.environ):
+    """(rank, local_rank, world) as torch.distributed.run / bench.py's own launcher export them"""
+    return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", env.get("RANK", "0"))), int(env.get("WORLD_SIZE", "1"))
 
 
-def broadcast_keyframe(kf, src: int, dist=None):
-    """kf = dict(pose (3,), velocity (3,), features (K,2) f32, peaks (P,2) i32) on rank `src`
-    (ignored elsewhere); returns the same dict on every rank."""
-    import torch
-    if dist is None:
-        import torch.distributed as dist
-    dev = _device(dist)
-    me = dist.get_rank()
-    hdr = torch.zeros(2, dtype=torch.int64, device=dev)
-    if me == src:
-        feats = np.ascontiguousarray(kf["features"], np.float32).reshape(-1, 2)
-        peaks = np.ascontiguousarray(kf["peaks"], np.int32).reshape(-1, 2)
-        hdr[0], hdr[1] = feats.shape[0], peaks.shape[0]
-    dist.broadcast(hdr, src)
-    K, P = int(hdr[0].item()), int(hdr[1].item())
-    nbytes = 48 + K * 8 + P * 8
-    if me == src:
-        buf = np.empty(nbytes, np.uint8)
-        buf[:24] = np.ascontiguousarray(kf["pose"], np.float64).view(np.uint8)
-        buf[24:48] = np.ascontiguousarray(kf["velocity"], np.float64).view(np.uint8)
-        buf[48:48 + K * 8] = feats.view(np.uint8).reshape(-1)
-        buf[48 + K * 8:] = peaks.view(np.uint8).reshape(-1)
-        t = torch.from_numpy(buf).to(dev)
-    else:
-        t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    dist.broadcast(t, src)
-    b = t.cpu().numpy()
-    return dict(pose=b[:24].view(np.float64).copy(), velocity=b[24:48].view(np.float64).copy(),
-                features=b[48:48 + K * 8].view(np.float32).reshape(K, 2).copy(),
-                peaks=b[48 + K * 8:].view(np.int32).reshape(P, 2).copy())
+def rendezvous_dir(env=os.environ) -> str:
+    """One directory per launch: ROAM_RDV_DIR if the launcher set it, otherwise derived from what all ranks of one
+    torch.distributed.run launch share (the agent's pid and the master port)."""
+    d = env.get("ROAM_RDV_DIR")
+    if not d:
+        d = os.path.join(env.get("TMPDIR", "/tmp"), f"roam_rdv_{os.getppid()}_{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+class FileRendezvous:
+    """Tiny key/value exchange between the ranks of one node through a directory (atomic rename on write)."""
+
+    def __init__(self, path: str, rank: int, world: int, timeout: float = 300.0):
+        self.path, self.rank, self.world, self.timeout = path, rank, world, timeout
+        self._seq = 0
+
+    def put(self, key: str, data: bytes):
+        tmp = os.path.join(self.path, f".{key}.{self.rank}.tmp")
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, os.path.join(self.path, f"{key}.{self.rank}"))
+
+    def get(self, key: str, rank: int) -> bytes:
+        p = os.path.join(self.path, f"{key}.{rank}")
+        t0 = time.monotonic()
+        while not os.path.exists(p):
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError(f"rendezvous: {p} did not appear within {self.timeout} s")
+            time.sleep(0.002)
+        with open(p, "rb") as f:
+            return f.read()
+
+    def gather(self, tag: str, data: bytes):
+        """every rank contributes `data`; returns the list of all contributions (also a barrier)"""
+        self._seq += 1
+        key = f"{tag}_{self._seq}"
+        self.put(key, data)
+        return [self.get(key, r) for r in range(self.world)]
+
+    def cleanup(self):
+        """collective: every rank signs off; rank 0 removes the directory once nobody reads it any more"""
+        self.put("done", b"1")
+        if self.rank == 0:
+            for r in range(self.world):
+                self.get("done", r)
+            for f in os.listdir(self.path):
+                try:
+                    os.unlink(os.path.join(self.path, f))
+                except OSError:
+                    pass
+            try:
+                os.rmdir(self.path)
+            except OSError:
+                pass
+
+
+class FileComm:
+    """CPU stand-in with RcclComm's interface (bench.py --dry-engine and the CPU tests only)."""
+    backend = "file"
+
+    def __init__(self, rdv: FileRendezvous):
+        self.rdv, self.rank, self.world = rdv, rdv.rank, rdv.world
+
+    def info(self):
+        return self.rank, self.world
+
+    def barrier(self):
+        self.rdv.gather("barrier", b"1")
+
+    def allreduce_max(self, value: float) -> float:
+        return max(float(x) for x in self.rdv.gather("max", repr(float(value)).encode()))
+
+    def bcast_keyframe(self, engine, root: int, lane: int) -> dict:
+        self.rdv._seq += 1
+        key = f"kf_{self.rdv._seq}"
+        if self.rank == root:
+            kf = engine.live_keyframe(lane)
+            blob = json.dumps({k: np.asarray(v).tolist() for k, v in kf.items()}).encode()
+            self.rdv.put(key, blob)
+        d = json.loads(self.rdv.get(key, root))
+        self.barrier()
+        return dict(pose=np.array(d["pose"], np.float64), velocity=np.array(d["velocity"], np.float64),
+                    prunedUndistortedLocals=np.array(d["prunedUndistortedLocals"], np.float64).reshape(-1, 2),
+                    peaks=np.array(d["peaks"], np.int32).reshape(-1, 2), scan=int(d["scan"]), lane=int(d["lane"]))
+
+    def close(self):
+        self.barrier()
+        self.rdv.cleanup()
+
+
+class RcclComm:
+    """RCCL communicator of one context (roam_comm_*): ncclUniqueId of rank 0 travels through the rendezvous directory."""
+    backend = "rccl"
+
+    def __init__(self, ctx, rdv: FileRendezvous):
+        import ctypes as C
+        from . import _ffi
+        self.ctx, self.rdv, self.rank, self.world = ctx, rdv, rdv.rank, rdv.world
+        self._C, self._ffi = C, _ffi
+        if self.rank == 0:
+            ident = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
+            rc = ctx.lib.roam_comm_unique_id(ident)
+            if rc != _ffi.ROAM_OK:
+                raise _ffi.RoamError(rc, "roam_comm_unique_id failed (librccl.so missing?)")
+            rdv.put("rccl_id", bytes(ident))
+        raw = rdv.get("rccl_id", 0)
+        assert len(raw) == _ffi.COMM_ID_BYTES
+        ident = (C.c_uint8 * _ffi.COMM_ID_BYTES).from_buffer_copy(raw)
+        ctx.check(ctx.lib.roam_comm_init(ctx.h, ident, self.rank, self.world))
+
+    def info(self):
+        """(rank, world) as RCCL itself reports them"""
+        r, w = self._C.c_int32(-1), self._C.c_int32(-1)
+        self.ctx.check(self.ctx.lib.roam_comm_info(self.ctx.h, self._C.byref(r), self._C.byref(w)))
+        return r.value, w.value
+
+    def barrier(self):
+        self.ctx.check(self.ctx.lib.roam_comm_barrier(self.ctx.h))
+
+    def allreduce_max(self, value: float) -> float:
+        v = (self._C.c_double * 1)(float(value))
+        self.ctx.check(self.ctx.lib.roam_comm_allreduce_f64(self.ctx.h, v, 1, 0))
+        return float(v[0])
+
+    def bcast_keyframe(self, engine, root: int, lane: int) -> dict:
+        """collective: the live keyframe of `lane` on rank `root`, received from HBM to HBM on every rank"""
+        C, _ffi = self._C, self._ffi
+        hdr = _ffi.KeyframeHdr()
+        loc = np.empty((_ffi.MAX_FEATURES, 2), np.float64)
+        cap = engine.cfg.peaks_cap
+        pk = np.empty((cap, 2), np.int32)
+        self.ctx.check(self.ctx.lib.roam_bcast_keyframe(self.ctx.h, int(root), int(lane), C.byref(hdr), _ffi._ptr(loc), loc.shape[0],
+                                                        _ffi._ptr(pk), cap))
+        return dict(pose=np.array(hdr.pose[:]), velocity=np.array(hdr.velocity[:]),
+                    prunedUndistortedLocals=loc[:hdr.n_features].copy(), peaks=pk[:hdr.n_peaks].copy(), scan=hdr.scan, lane=hdr.lane)
+
+    def close(self):
+        self.barrier()
+        self.ctx.check(self.ctx.lib.roam_comm_destroy(self.ctx.h))
+        self.rdv.cleanup()

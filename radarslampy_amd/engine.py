@@ -78,6 +78,12 @@ class Engine:
                                                     _ffi._ptr(loc), loc.shape[0], C.byref(n), C.byref(sc)))
         return dict(pose=pose, velocity=vel, prunedUndistortedLocals=loc[:n.value].copy(), scan=sc.value)
 
+    def live_keyframe(self, lane: int) -> dict:
+        """the keyframe the tracker is pruning right now (Mapping.Map.keyframes[-1]) + the latest polar point cloud"""
+        kf = self.map_keyframe(lane, self.map_count(lane) - 1)
+        kf.update(peaks=self.lane_peaks(lane), lane=lane)
+        return kf
+
     def map_keyframes(self, lane: int):
         return [self.map_keyframe(lane, i) for i in range(self.map_count(lane))]
 

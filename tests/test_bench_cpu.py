@@ -1,43 +1,49 @@
-"""CPU (-m "not gpu"): bench.py's multi-rank plumbing with gloo and a stub engine (no GPU): the
-barrier / max-over-ranks reduction / keyframe broadcast code path that the driver launches with
-torch.distributed.run is exercised at world_size 2."""
+"""CPU (-m "not gpu"): bench.py's REAL multi-rank code path - its own `--gpus N` launcher and the torch.distributed.run
+launch the driver uses - with `--dry-engine` (a stub instead of the GPU engine; rendezvous, rank environment handling,
+barrier, max-over-ranks time, keyframe broadcast bookkeeping and the one-JSON-line contract are the real code)."""
 import json
 import os
 import subprocess
 import sys
-import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+ARGS = ["--dry-engine", "--steps", "4", "--warmup", "1", "--lanes", "8"]
 
 
-def test_bench_distributed_plumbing_world2(tmp_path):
-    stub = tmp_path / "stub_bench.py"
-    stub.write_text(textwrap.dedent(f"""
-        import os, sys, time, json
-        sys.path.insert(0, {ROOT!r})
-        import numpy as np
-        import torch, torch.distributed as dist
-        from radarslampy_amd.distributed import broadcast_keyframe, shard_sequences
-        dist.init_process_group("gloo")
-        rank, world = dist.get_rank(), dist.get_world_size()
-        dist.barrier()
-        t0 = time.perf_counter(); time.sleep(0.05 * (rank + 1)); dist.barrier()
-        dt = time.perf_counter() - t0
-        tt = torch.tensor([dt]); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        mine = dict(pose=np.arange(3.0) + rank, velocity=np.zeros(3), features=np.full((5 + rank, 2), rank, np.float32),
-                    peaks=np.full((7, 2), rank, np.int32))
-        ok = True
-        for src in range(world):
-            got = broadcast_keyframe(mine if rank == src else None, src, dist)
-            ok &= got["features"].shape == (5 + src, 2) and float(got["pose"][0]) == float(src)
-        if rank == 0:
-            print(json.dumps({{"n_gpus": world, "max_dt": float(tt.item()), "ok": bool(ok), "mine": shard_sequences(8, rank, world)}}))
-        dist.barrier(); dist.destroy_process_group()
-    """))
+def _line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout                      # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def _check(d, world, launcher):
+    assert d["n_gpus"] == world and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["lanes_per_gpu"] == 8 and d["config"]["launcher"] == launcher
+    # max over ranks: the stub's rank r sleeps 2 ms * (r + 1) per step
+    assert d["ms_per_step"] >= 2.0 * world * 0.9
+    assert abs(d["value"] - 8 * 4 * world / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-3
+    if world > 1:
+        assert d["config"]["collective_backend"] == "file" and d["config"]["comm_rank_world_seen"] == [0, world]
+        assert d["config"]["keyframe_broadcast_ms"] is not None
+
+
+def test_bench_single_process_dry():
+    r = subprocess.run([sys.executable, BENCH] + ARGS, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(_line(r.stdout), 1, "single process")
+
+
+def test_bench_own_launcher_world2():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(_line(r.stdout), 2, "bench.py --gpus")
+
+
+def test_bench_under_torch_distributed_run_world2():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", str(stub)], capture_output=True, text=True, timeout=300, env=env)
+                        "--master-port", "29631", BENCH, "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["ok"] and d["max_dt"] >= 0.1 and d["mine"] == [0, 2, 4, 6]
+    _check(_line(r.stdout), 2, "torch.distributed.run env")

@@ -297,3 +297,37 @@ def test_engine_pipelined_steps_match_synchronised_steps(sequences):
         for x, y in zip(a[k], b[k]):
             assert np.array_equal(x, y), k
     ctx.close()
+
+
+def test_rccl_keyframe_broadcast_world1(sequences):
+    """8e: the native RCCL path (roam_comm_* / roam_bcast_keyframe) on one GPU: communicator of size 1, all-reduce,
+    barrier, and the keyframe payload packed on the device, broadcast and read back == the engine's own accessors"""
+    import tempfile
+    from radarslampy_amd import _ffi
+    from radarslampy_amd import distributed as D
+    from radarslampy_amd.engine import Engine
+    ctx = _ffi.Context(0)
+    B, T = len(sequences), 4
+    eng = Engine(B, B * T, ctx=ctx)
+    for b, (recs, poses, feat) in enumerate(sequences):
+        for t in range(T):
+            eng.upload_scan(b * T + t, recs[t])
+        eng.init_lane(b, b * T, feat, poses[0])
+    eng.step([b * T + 1 for b in range(B)])
+    eng.step([b * T + 2 for b in range(B)])
+    comm = D.RcclComm(ctx, D.FileRendezvous(tempfile.mkdtemp(prefix="roam_rdv_"), 0, 1))
+    try:
+        assert comm.info() == (0, 1)
+        assert comm.allreduce_max(0.125) == 0.125
+        comm.barrier()
+        for lane in (0, B - 1):
+            got = comm.bcast_keyframe(eng, 0, lane)
+            want = eng.live_keyframe(lane)
+            assert got["lane"] == lane and got["scan"] == want["scan"]
+            for k in ("pose", "velocity", "prunedUndistortedLocals", "peaks"):
+                assert np.array_equal(got[k], want[k]), k
+            assert len(got["peaks"]) > 1000 and len(got["prunedUndistortedLocals"]) > 20
+    finally:
+        comm.close()
+    eng.close()
+    ctx.close()
