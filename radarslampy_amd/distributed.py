@@ -116,6 +116,23 @@ class FileComm:
         self.rdv.cleanup()
 
 
+class _stdout_to_stderr:
+    """librccl prints a version banner on file descriptor 1 while the communicator is created; a program whose stdout is a
+    protocol (bench.py: ONE JSON line) parks fd 1 on stderr for that moment (and flushes C stdio before un-parking)"""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)                 # the banner sits in C stdio's buffer: flush it while fd 1 is parked
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 class RcclComm:
     """RCCL communicator of one context (roam_comm_*): ncclUniqueId of rank 0 travels through the rendezvous directory."""
     backend = "rccl"
@@ -134,7 +151,9 @@ class RcclComm:
         raw = rdv.get("rccl_id", 0)
         assert len(raw) == _ffi.COMM_ID_BYTES
         ident = (C.c_uint8 * _ffi.COMM_ID_BYTES).from_buffer_copy(raw)
-        ctx.check(ctx.lib.roam_comm_init(ctx.h, ident, self.rank, self.world))
+        with _stdout_to_stderr():
+            ctx.check(ctx.lib.roam_comm_init(ctx.h, ident, self.rank, self.world))
+            ctx.check(ctx.lib.roam_comm_barrier(ctx.h))          # first collective: channels are set up here
 
     def info(self):
         """(rank, world) as RCCL itself reports them"""
