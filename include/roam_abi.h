@@ -133,6 +133,16 @@ int32_t roam_doh_maxima(roam_ctx *ctx, const float *img, int32_t w, int32_t h, c
                         int32_t num_sigma, double threshold, int32_t *out_rcs, double *out_val,
                         int32_t cap, int32_t *n_out);
 
+/* ---- a4/a5 bookkeeping whose ORDER the reference's pinned third-party stack fixes (host code, no GPU; the engine's
+ * device-side retrack runs the same functions on the GPU):
+ * roam_prune_blobs   = skimage.feature.blob._prune_blobs as blob_doh calls it (getFeatures.py:47-51): candidate pairs in the
+ *                      iteration order of the Python set that scipy cKDTree.query_pairs fills.  blobs (n,3) f64 rows
+ *                      [row, col, sigma] in peak_local_max order, integer rows / cols; keep_out (n) u8.
+ * roam_argsort_np122 = np.argsort of the pinned NumPy 1.22.3 (unstable introsort) that adaptiveNMS applies to the
+ *                      two-valued sigmas (getFeatures.py:69); order_out (n) i32. */
+int32_t roam_prune_blobs(const double *blobs, int32_t n, double overlap, uint8_t *keep_out);
+int32_t roam_argsort_np122(const double *keys, int32_t n, int32_t *order_out);
+
 /* ---- engine: B resident lanes, one scan pair per lane per step ---------------------------
  * Replaces the body of the RawROAMSystem.run loop (RawROAMSystem.py:162-298) minus plotting:
  * a1/a2 ingest+peaks, a3 warp+quantise, pyramid, a7 KLT against the lane's previous

@@ -83,6 +83,8 @@ _SIGS = {
     "roam_engine_map_get": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "roam_engine_stage_times": (C.c_int32, [_vp, _vp, _P(C.c_char_p), C.c_int32, _P(C.c_int32)]),
     "roam_engine_time_kernel": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_float), _P(C.c_double)]),
+    "roam_prune_blobs": (C.c_int32, [_vp, C.c_int32, C.c_double, _vp]),
+    "roam_argsort_np122": (C.c_int32, [_vp, C.c_int32, _vp]),
     "roam_comm_unique_id": (C.c_int32, [_vp]),
     "roam_comm_init": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
     "roam_comm_destroy": (C.c_int32, [_vp]),

@@ -1,0 +1,447 @@
+// blobprune.h - the ORDER-DEPENDENT bookkeeping of the reference's feature detection, restated so that one piece of
+// code serves the host entry points (roam_prune_blobs, roam_argsort_np122: radarslampy_amd/getFeatures.py) and the
+// device-side retrack of the engine (retrack.hip, one wavefront per lane; the sequential parts run on lane 0 with
+// their working set in LDS).
+//
+//   skimage.feature.blob._prune_blobs (called by blob_doh, reference getFeatures.py:47-51) visits the overlapping
+//   candidate pairs in the iteration order of a Python SET filled from scipy.spatial.cKDTree.query_pairs; chains of
+//   overlapping blobs make the survivors depend on that order (0-3 blobs of ~420 per real frame).  Reproduced here:
+//     bp_build / bp_tasks : cKDTree build (leafsize 16, median split = libstdc++ nth_element on the coordinate, then the
+//                           Hoare-style split pass; compact bounds) and the dual-tree traversal of query_pairs with its
+//                           RectRectDistanceTracker (p = 2) -> the ordered list of leaf x leaf blocks
+//     bp_expand           : the pairs of those blocks in emission order          (wave-parallel on the device)
+//     bp_pyset_order      : CPython >= 3.8 set of (i, j) tuples: xxHash-style tuple hash, 9 linear probes +
+//                           perturbation, growth to > 4 x used; iteration = table order
+//   getFeatures.adaptiveNMS (getFeatures.py:66-72) sorts the blobs by a sigma that takes two values with NumPy's
+//   default UNSTABLE argsort; the reference pins numpy 1.22.3 = npy_aquicksort, restated in bp_aquicksort.
+// Coordinates are integer pixel indices (DoH maxima), so every comparison on them is exact in any arithmetic type.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BP_HD __host__ __device__ __forceinline__
+#define BP_HDN __host__ __device__
+#else
+#define BP_HD inline
+#define BP_HDN inline
+#endif
+
+#define BP_MAX_PTS 2048          // candidates per problem
+#define BP_LEAF 16
+#define BP_MAX_NODES 640
+#define BP_MAX_TASKS 8192
+#define BP_MAX_PAIRS 32767       // pair indices are stored +1 in 16-bit set tables
+#define BP_LDS_PAIRS 4914        // below this count the set never grows past 8192 entries (LDS fast path)
+
+struct BpNode { int32_t split; int16_t split_dim, start, end, less, greater; };
+struct BpTask { int16_t a, b; int32_t mode; };            // leaf a x leaf b; mode 1 = every pair (no distance test)
+
+// ------------------------------------------------------------------------------------------------ nth_element
+// libstdc++ std::nth_element (introselect) on an index array, comparator = coordinate value only (scipy's)
+#define BP_KEY(i) (xy[2 * (int)(i) + d])
+template <typename IDX>
+BP_HDN void bp_adjust_heap(IDX *f, int hole, int len, IDX value, const int16_t *xy, int d)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (BP_KEY(f[child]) < BP_KEY(f[child - 1])) child--;
+        f[hole] = f[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        f[hole] = f[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && BP_KEY(f[parent]) < BP_KEY(value)) {
+        f[hole] = f[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    f[hole] = value;
+}
+
+template <typename IDX>
+BP_HDN void bp_nth_element(IDX *idx, int first, int nth, int last, const int16_t *xy, int d)
+{
+    if (first == last || nth == last) return;
+    int depth = 0;
+    for (int n = last - first; n > 1; n >>= 1) depth++;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {                                   // __heap_select(first, nth + 1, last) + swap
+            IDX *f = idx + first;
+            const int len = nth + 1 - first;
+            if (len >= 2)
+                for (int parent = (len - 2) / 2;; parent--) { bp_adjust_heap(f, parent, len, f[parent], xy, d); if (parent == 0) break; }
+            for (int i = nth + 1; i < last; i++)
+                if (BP_KEY(idx[i]) < BP_KEY(f[0])) { IDX v = idx[i]; idx[i] = f[0]; bp_adjust_heap(f, 0, len, v, xy, d); }
+            IDX t = idx[first]; idx[first] = idx[nth]; idx[nth] = t;
+            return;
+        }
+        depth--;
+        const int mid = first + (last - first) / 2;
+        const int a = first + 1, b = mid, c = last - 1;
+        int s;                                              // __move_median_to_first
+        if (BP_KEY(idx[a]) < BP_KEY(idx[b])) s = BP_KEY(idx[b]) < BP_KEY(idx[c]) ? b : (BP_KEY(idx[a]) < BP_KEY(idx[c]) ? c : a);
+        else s = BP_KEY(idx[a]) < BP_KEY(idx[c]) ? a : (BP_KEY(idx[b]) < BP_KEY(idx[c]) ? c : b);
+        { IDX t = idx[first]; idx[first] = idx[s]; idx[s] = t; }
+        int f = first + 1, l = last;                        // __unguarded_partition
+        const int piv = BP_KEY(idx[first]);
+        for (;;) {
+            while (BP_KEY(idx[f]) < piv) f++;
+            l--;
+            while (piv < BP_KEY(idx[l])) l--;
+            if (!(f < l)) break;
+            IDX t = idx[f]; idx[f] = idx[l]; idx[l] = t;
+            f++;
+        }
+        if (f <= nth) first = f; else last = f;
+    }
+    for (int i = first + 1; i < last; i++) {                // __insertion_sort
+        const IDX v = idx[i];
+        if (BP_KEY(v) < BP_KEY(idx[first])) { for (int j = i; j > first; j--) idx[j] = idx[j - 1]; idx[first] = v; }
+        else { int j = i; while (BP_KEY(v) < BP_KEY(idx[j - 1])) { idx[j] = idx[j - 1]; j--; } idx[j] = v; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cKDTree build
+// xy: n x 2 int16 [row, col]; idx: n (filled 0..n-1 here); returns the node count or -1 on overflow.
+// stack: caller-provided scratch of 3 * 64 ints; node_cap: capacity of nodes (BP_MAX_NODES in LDS on the device).
+template <typename IDX>
+BP_HDN int bp_build(const int16_t *xy, int n, IDX *idx, BpNode *nodes, int node_cap, int *stack)
+{
+    for (int i = 0; i < n; i++) idx[i] = (IDX)i;
+    int nn = 0, sp = 0;
+    stack[0] = 0; stack[1] = n; stack[2] = -1; sp = 1;      // (start, end, parent*2 + is_greater)
+    while (sp) {
+        sp--;
+        const int start = stack[3 * sp], end = stack[3 * sp + 1], link = stack[3 * sp + 2];
+        if (nn >= node_cap) return -1;
+        const int me = nn++;
+        if (link >= 0) { if (link & 1) nodes[link >> 1].greater = (int16_t)me; else nodes[link >> 1].less = (int16_t)me; }
+        BpNode nd;
+        nd.start = (int16_t)start; nd.end = (int16_t)end; nd.less = nd.greater = -1; nd.split_dim = -1; nd.split = 0;
+        if (end - start > BP_LEAF) {
+            int mx0 = xy[2 * idx[start]], mn0 = mx0, mx1 = xy[2 * idx[start] + 1], mn1 = mx1;   // compact_nodes bounds
+            for (int j = start + 1; j < end; j++) {
+                const int v0 = xy[2 * idx[j]], v1 = xy[2 * idx[j] + 1];
+                mx0 = v0 > mx0 ? v0 : mx0; mn0 = v0 < mn0 ? v0 : mn0;
+                mx1 = v1 > mx1 ? v1 : mx1; mn1 = v1 < mn1 ? v1 : mn1;
+            }
+            int d = 0, size = 0;
+            if (mx0 - mn0 > size) { d = 0; size = mx0 - mn0; }
+            if (mx1 - mn1 > size) { d = 1; size = mx1 - mn1; }
+            if (size > 0) {
+                const int i = (end - start) / 2;
+                bp_nth_element(idx, start, start + i, end, xy, d);
+                int split = BP_KEY(idx[start + i]);
+                int p = start, q = end - 1;
+                while (p <= q) {
+                    if (BP_KEY(idx[p]) < split) p++;
+                    else if (BP_KEY(idx[q]) >= split) q--;
+                    else { IDX t = idx[p]; idx[p] = idx[q]; idx[q] = t; p++; q--; }
+                }
+                if (p == start) {                           // no point below the split: slide to the smallest
+                    int j = start; split = BP_KEY(idx[j]);
+                    for (int k = start + 1; k < end; k++) if (BP_KEY(idx[k]) < split) { j = k; split = BP_KEY(idx[j]); }
+                    IDX t = idx[start]; idx[start] = idx[j]; idx[j] = t;
+                    p = start + 1;
+                } else if (p == end) {
+                    int j = end - 1; split = BP_KEY(idx[j]);
+                    for (int k = start; k < end - 1; k++) if (BP_KEY(idx[k]) > split) { j = k; split = BP_KEY(idx[j]); }
+                    IDX t = idx[end - 1]; idx[end - 1] = idx[j]; idx[j] = t;
+                    p = end - 1;
+                }
+                nd.split_dim = (int16_t)d; nd.split = split;
+                if (sp + 2 > 64) return -1;
+                stack[3 * sp] = p; stack[3 * sp + 1] = end; stack[3 * sp + 2] = 2 * me + 1; sp++;     // greater: built after
+                stack[3 * sp] = start; stack[3 * sp + 1] = p; stack[3 * sp + 2] = 2 * me; sp++;       // the whole less subtree
+            }
+        }
+        nodes[me] = nd;
+    }
+    return nn;
+}
+#undef BP_KEY
+
+// ------------------------------------------------------------------------------------------------ query_pairs traversal
+struct BpTracker {
+    double r1[2][2], r2[2][2];     // [min|max][dim] of the two current boxes
+    double mind, maxd, ub, limit;
+    double s_mind[48], s_maxd[48], s_lo[48], s_hi[48];
+    int s_which[48], s_dim[48], sp;
+};
+
+BP_HD void bp_tdim(const BpTracker &t, int k, double *mn, double *mx)
+{
+    const double a0 = t.r1[0][k], a1 = t.r1[1][k], b0 = t.r2[0][k], b1 = t.r2[1][k];
+    double lo = a0 - b1 > b0 - a1 ? a0 - b1 : b0 - a1;
+    if (lo < 0) lo = 0;
+    const double hi = a1 - b0 > b1 - a0 ? a1 - b0 : b1 - a0;
+    *mn = lo * lo; *mx = hi * hi;
+}
+BP_HD void bp_tfull(BpTracker &t)
+{
+    double a, b, c, d;
+    bp_tdim(t, 0, &a, &b); bp_tdim(t, 1, &c, &d);
+    t.mind = a + c; t.maxd = b + d;
+}
+BP_HD void bp_tpush(BpTracker &t, int which, int less, int dim, double split)
+{
+    double (*rect)[2] = which == 1 ? t.r1 : t.r2;
+    const int s = t.sp++;
+    t.s_which[s] = which; t.s_dim[s] = dim; t.s_mind[s] = t.mind; t.s_maxd[s] = t.maxd; t.s_lo[s] = rect[0][dim]; t.s_hi[s] = rect[1][dim];
+    double min1, max1, min2, max2;
+    bp_tdim(t, dim, &min1, &max1);
+    if (less) rect[1][dim] = split; else rect[0][dim] = split;
+    bp_tdim(t, dim, &min2, &max2);
+    const double L = t.limit;
+    if (t.mind < L || t.maxd < L || (min1 != 0 && min1 < L) || max1 < L || (min2 != 0 && min2 < L) || max2 < L) bp_tfull(t);
+    else { t.mind += (min2 - min1); t.maxd += (max2 - max1); }
+}
+BP_HD void bp_tpop(BpTracker &t)
+{
+    const int s = --t.sp;
+    double (*rect)[2] = t.s_which[s] == 1 ? t.r1 : t.r2;
+    t.mind = t.s_mind[s]; t.maxd = t.s_maxd[s]; rect[0][t.s_dim[s]] = t.s_lo[s]; rect[1][t.s_dim[s]] = t.s_hi[s];
+}
+
+// ops of the explicit traversal stack (three ints each): the recursion of query_pairs.cxx unrolled
+enum { BP_CHECK = 0, BP_NOCHECK = 1, BP_PUSH = 2, BP_POP = 3 };
+#define BP_ST(o, x, y) do { if (sp >= cap) return -1; st[3 * sp] = (o); st[3 * sp + 1] = (x); st[3 * sp + 2] = (y); sp++; } while (0)
+
+// tasks: leaf x leaf blocks in emission order.  st: scratch of 3 * cap ints.  returns the task count or -1 on overflow.
+BP_HDN int bp_tasks(const int16_t *xy, int n, const BpNode *nodes, double r, BpTask *tasks, int task_cap, int *st, int cap, BpTracker &tr)
+{
+    int mn0 = xy[0], mx0 = mn0, mn1 = xy[1], mx1 = mn1;
+    for (int i = 1; i < n; i++) {
+        const int v0 = xy[2 * i], v1 = xy[2 * i + 1];
+        mx0 = v0 > mx0 ? v0 : mx0; mn0 = v0 < mn0 ? v0 : mn0; mx1 = v1 > mx1 ? v1 : mx1; mn1 = v1 < mn1 ? v1 : mn1;
+    }
+    tr.r1[0][0] = tr.r2[0][0] = mn0; tr.r1[1][0] = tr.r2[1][0] = mx0;
+    tr.r1[0][1] = tr.r2[0][1] = mn1; tr.r1[1][1] = tr.r2[1][1] = mx1;
+    tr.ub = r * r; tr.sp = 0;
+    bp_tfull(tr);
+    tr.limit = tr.maxd;
+    int nt = 0, sp = 0;
+    BP_ST(BP_CHECK, 0, 0);
+    while (sp) {
+        sp--;
+        const int op = st[3 * sp], a = st[3 * sp + 1], b = st[3 * sp + 2];
+        if (op == BP_POP) { bp_tpop(tr); continue; }
+        if (op == BP_PUSH) {                                  // a = which | less << 1, b = node whose split plane is applied
+            if (tr.sp >= 48) return -1;
+            bp_tpush(tr, a & 1 ? 1 : 2, (a >> 1) & 1, nodes[b].split_dim, (double)nodes[b].split);
+            continue;
+        }
+        const BpNode &n1 = nodes[a], &n2 = nodes[b];
+        const bool l1 = n1.split_dim == -1, l2 = n2.split_dim == -1;
+        if (op == BP_NOCHECK) {
+            if (l1 && l2) { if (nt >= task_cap) return -1; tasks[nt].a = (int16_t)a; tasks[nt].b = (int16_t)b; tasks[nt].mode = 1; nt++; }
+            else if (l1) { BP_ST(BP_NOCHECK, a, n2.greater); BP_ST(BP_NOCHECK, a, n2.less); }
+            else if (a == b) { BP_ST(BP_NOCHECK, n1.greater, n2.greater); BP_ST(BP_NOCHECK, n1.less, n2.greater); BP_ST(BP_NOCHECK, n1.less, n2.less); }
+            else { BP_ST(BP_NOCHECK, n1.greater, b); BP_ST(BP_NOCHECK, n1.less, b); }
+            continue;
+        }
+        if (tr.mind > tr.ub) continue;
+        if (tr.maxd < tr.ub) { BP_ST(BP_NOCHECK, a, b); continue; }
+        // which | less<<1 encodings: box 1 less = 3, box 1 greater = 1, box 2 less = 2, box 2 greater = 0
+        if (l1 && l2) { if (nt >= task_cap) return -1; tasks[nt].a = (int16_t)a; tasks[nt].b = (int16_t)b; tasks[nt].mode = 0; nt++; }
+        else if (l1) {
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, a, n2.greater); BP_ST(BP_PUSH, 0, b);
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, a, n2.less); BP_ST(BP_PUSH, 2, b);
+        } else if (l2) {
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, n1.greater, b); BP_ST(BP_PUSH, 1, a);
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, n1.less, b); BP_ST(BP_PUSH, 3, a);
+        } else {                                            // pushed in reverse order of execution
+            BP_ST(BP_POP, 0, 0);
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, n1.greater, n2.greater); BP_ST(BP_PUSH, 0, b);
+            if (a != b) { BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, n1.greater, n2.less); BP_ST(BP_PUSH, 2, b); }
+            BP_ST(BP_PUSH, 1, a);
+            BP_ST(BP_POP, 0, 0);
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, n1.less, n2.greater); BP_ST(BP_PUSH, 0, b);
+            BP_ST(BP_POP, 0, 0); BP_ST(BP_CHECK, n1.less, n2.less); BP_ST(BP_PUSH, 2, b);
+            BP_ST(BP_PUSH, 3, a);
+        }
+    }
+    return nt;
+}
+#undef BP_ST
+
+// pair (i < j) packed as i << 16 | j
+BP_HD uint32_t bp_pack(int i, int j) { return i < j ? ((uint32_t)i << 16) | (uint32_t)j : ((uint32_t)j << 16) | (uint32_t)i; }
+
+// sequential expansion of the tasks (host; the device does the same with ballots over 64 candidates at a time)
+template <typename IDX>
+inline int bp_expand(const int16_t *xy, const IDX *idx, const BpNode *nodes, const BpTask *tasks, int nt, double ub, uint32_t *pairs, int cap)
+{
+    int np = 0;
+    for (int t = 0; t < nt; t++) {
+        const BpNode &n1 = nodes[tasks[t].a], &n2 = nodes[tasks[t].b];
+        for (int i = n1.start; i < n1.end; i++)
+            for (int j = (tasks[t].a == tasks[t].b ? i + 1 : n2.start); j < n2.end; j++) {
+                const int pi = idx[i], pj = idx[j];
+                const double d0 = (double)xy[2 * pi] - (double)xy[2 * pj], d1 = (double)xy[2 * pi + 1] - (double)xy[2 * pj + 1];
+                if (tasks[t].mode || d0 * d0 + d1 * d1 <= ub) { if (np >= cap) return -1; pairs[np++] = bp_pack(pi, pj); }
+            }
+    }
+    return np;
+}
+
+// ------------------------------------------------------------------------------------------------ CPython set order
+BP_HD uint64_t bp_tuple_hash(uint32_t packed)
+{
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P5 = 2870177450012600261ULL;
+    uint64_t acc = P5;
+    acc += (uint64_t)(packed >> 16) * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += (uint64_t)(packed & 0xffffu) * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += 2ULL ^ (P5 ^ 3527539ULL);
+    return acc == ~0ULL ? 1546275796ULL : acc;
+}
+
+// first free slot of key's probe sequence (set_add_entry / set_insert_clean: the keys are distinct, so no compare)
+BP_HD void bp_set_put(uint16_t *tab, uint32_t mask, uint64_t hash, uint16_t key1)
+{
+    uint64_t perturb = hash;
+    uint32_t i = (uint32_t)hash & mask;
+    for (;;) {
+        int probes = (i + 9 <= mask) ? 9 : 0;
+        uint32_t e = i;
+        do { if (tab[e] == 0) { tab[e] = key1; return; } e++; } while (probes--);
+        perturb >>= 5;
+        i = (uint32_t)(((uint64_t)i * 5 + 1 + perturb) & mask);
+    }
+}
+
+// order (np) = indices into pairs in the iteration order of the Python set built by adding them in sequence.
+// tabA / tabB: ping-pong tables; capacities (entries) capA >= 2048 and capB >= 8192 suffice for np <= BP_LDS_PAIRS,
+// both >= 131072 for np <= BP_MAX_PAIRS.  Tables hold pair index + 1 (0 = empty).  returns np, or -1 if a table is too small.
+template <typename ORD>
+BP_HDN int bp_pyset_order(const uint32_t *pairs, int np, uint16_t *tabA, int capA, uint16_t *tabB, int capB, ORD *order)
+{
+    uint16_t *tab = tabA;
+    int cap_cur = capA, cap_other = capB;
+    uint16_t *other = tabB;
+    uint32_t mask = 7;
+    for (int k = 0; k < 8; k++) tab[k] = 0;
+    int fill = 0;
+    for (int p = 0; p < np; p++) {
+        bp_set_put(tab, mask, bp_tuple_hash(pairs[p]), (uint16_t)(p + 1));
+        fill++;
+        if ((uint64_t)fill * 5 >= (uint64_t)mask * 3) {
+            const int minused = fill > 50000 ? fill * 2 : fill * 4;
+            uint32_t newsize = 8;
+            while ((int)newsize <= minused) newsize <<= 1;
+            if ((int)newsize > cap_other) return -1;
+            for (uint32_t k = 0; k < newsize; k++) other[k] = 0;
+            for (uint32_t k = 0; k <= mask; k++)
+                if (tab[k]) bp_set_put(other, newsize - 1, bp_tuple_hash(pairs[tab[k] - 1]), tab[k]);
+            uint16_t *t = tab; tab = other; other = t;
+            const int c = cap_cur; cap_cur = cap_other; cap_other = c;
+            mask = newsize - 1;
+        }
+    }
+    int m = 0;
+    for (uint32_t k = 0; k <= mask; k++) if (tab[k]) order[m++] = (ORD)(tab[k] - 1);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------ _blob_overlap > thr
+// blobs [row, col, sigma] with the ORIGINAL sigmas (a pair with an already pruned member never changes anything)
+BP_HDN bool bp_overlaps(double r1_, double c1_, double s1, double r2_, double c2_, double s2, double thr)
+{
+    const double root2 = 1.4142135623730951;                // math.sqrt(2)
+    double r1, r2, ms;
+    if (s1 > s2) { ms = s1; r1 = 1.0; r2 = s2 / s1; }
+    else { ms = s2; r2 = 1.0; r1 = s1 / s2; }
+    const double den = ms * root2;
+    const double p0 = r1_ / den, p1 = c1_ / den, q0 = r2_ / den, q1 = c2_ / den;
+    const double d = sqrt((q0 - p0) * (q0 - p0) + (q1 - p1) * (q1 - p1));
+    if (d > r1 + r2) return false;
+    if (d <= fabs(r1 - r2)) return 1.0 > thr;
+    double ratio1 = (d * d + r1 * r1 - r2 * r2) / (2 * d * r1);
+    ratio1 = ratio1 < -1 ? -1 : (ratio1 > 1 ? 1 : ratio1);
+    double ratio2 = (d * d + r2 * r2 - r1 * r1) / (2 * d * r2);
+    ratio2 = ratio2 < -1 ? -1 : (ratio2 > 1 ? 1 : ratio2);
+    const double a = -d + r2 + r1, b = d - r2 + r1, c = d + r2 - r1, dd = d + r2 + r1;
+    const double area = r1 * r1 * acos(ratio1) + r2 * r2 * acos(ratio2) - 0.5 * sqrt(fabs(a * b * c * dd));
+    const double rmin = r1 < r2 ? r1 : r2;
+    return area / (3.141592653589793 * (rmin * rmin)) > thr;
+}
+
+// ------------------------------------------------------------------------------------------------ numpy 1.22 argsort
+// tosort (n) = np.argsort(key) of NumPy 1.22.3 (npy_aquicksort: median of 3, insertion sort below 17 elements, heapsort past
+// depth 2*floor(log2 n)).  KEY: any type with operator< (here: the sigma layer index, ordered like the sigma values).
+template <typename KEY, typename IDX>
+BP_HDN void bp_aheapsort(const KEY *v, IDX *tosort, int n)
+{
+    IDX *a = tosort - 1;
+    int i, j, l;
+    IDX tmp;
+    for (l = n >> 1; l > 0; --l) {
+        tmp = a[l];
+        for (i = l, j = l << 1; j <= n;) {
+            if (j < n && v[a[j]] < v[a[j + 1]]) j += 1;
+            if (v[tmp] < v[a[j]]) { a[i] = a[j]; i = j; j += j; } else break;
+        }
+        a[i] = tmp;
+    }
+    for (; n > 1;) {
+        tmp = a[n]; a[n] = a[1]; n -= 1;
+        for (i = 1, j = 2; j <= n;) {
+            if (j < n && v[a[j]] < v[a[j + 1]]) j++;
+            if (v[tmp] < v[a[j]]) { a[i] = a[j]; i = j; j += j; } else break;
+        }
+        a[i] = tmp;
+    }
+}
+
+template <typename KEY, typename IDX>
+BP_HDN void bp_aquicksort(const KEY *v, int num, IDX *tosort)
+{
+    for (int i = 0; i < num; i++) tosort[i] = (IDX)i;
+    if (num < 2) return;
+    int pl = 0, pr = num - 1, stack[128], sp = 0, depth[64], dp = 0, cdepth = 0;
+    for (int k = num; k > 1; k >>= 1) cdepth++;
+    cdepth *= 2;
+    for (;;) {
+        if (cdepth < 0) bp_aheapsort(v, tosort + pl, pr - pl + 1);
+        else {
+            while (pr - pl > 16) {
+                const int pm = pl + ((pr - pl) >> 1);
+                IDX t;
+                if (v[tosort[pm]] < v[tosort[pl]]) { t = tosort[pm]; tosort[pm] = tosort[pl]; tosort[pl] = t; }
+                if (v[tosort[pr]] < v[tosort[pm]]) { t = tosort[pr]; tosort[pr] = tosort[pm]; tosort[pm] = t; }
+                if (v[tosort[pm]] < v[tosort[pl]]) { t = tosort[pm]; tosort[pm] = tosort[pl]; tosort[pl] = t; }
+                const KEY vp = v[tosort[pm]];
+                int pi = pl, pj = pr - 1;
+                t = tosort[pm]; tosort[pm] = tosort[pj]; tosort[pj] = t;
+                for (;;) {
+                    do ++pi; while (v[tosort[pi]] < vp);
+                    do --pj; while (vp < v[tosort[pj]]);
+                    if (pi >= pj) break;
+                    t = tosort[pi]; tosort[pi] = tosort[pj]; tosort[pj] = t;
+                }
+                t = tosort[pi]; tosort[pi] = tosort[pr - 1]; tosort[pr - 1] = t;
+                if (pi - pl < pr - pi) { stack[sp++] = pi + 1; stack[sp++] = pr; pr = pi - 1; }
+                else { stack[sp++] = pl; stack[sp++] = pi - 1; pl = pi + 1; }
+                depth[dp++] = --cdepth;
+            }
+            for (int pi = pl + 1; pi <= pr; ++pi) {
+                const IDX vi = tosort[pi];
+                const KEY vp = v[vi];
+                int pj = pi;
+                while (pj > pl && vp < v[tosort[pj - 1]]) { tosort[pj] = tosort[pj - 1]; pj--; }
+                tosort[pj] = vi;
+            }
+        }
+        if (sp == 0) break;
+        pr = stack[--sp];
+        pl = stack[--sp];
+        cdepth = depth[--dp];
+    }
+}

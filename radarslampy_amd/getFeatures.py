@@ -1,7 +1,5 @@
 """Feature (re)detection with the reference's names (reference getFeatures.py:13-118):
 Determinant-of-Hessian blobs (doh.hip) + SSC-ANMS (ssc.hip) + dedupe-append."""
-import math
-
 import numpy as np
 
 from . import _ffi
@@ -16,51 +14,19 @@ def calculateFeatureLossThreshold(nInitialFeatures):
     return 80
 
 
-def _disk_overlap(d, r1, r2):
-    ratio1 = np.clip((d ** 2 + r1 ** 2 - r2 ** 2) / (2 * d * r1), -1, 1)
-    ratio2 = np.clip((d ** 2 + r2 ** 2 - r1 ** 2) / (2 * d * r2), -1, 1)
-    a, b, c, dd = -d + r2 + r1, d - r2 + r1, d + r2 - r1, d + r2 + r1
-    area = r1 ** 2 * math.acos(ratio1) + r2 ** 2 * math.acos(ratio2) - 0.5 * math.sqrt(abs(a * b * c * dd))
-    return area / (math.pi * (min(r1, r2) ** 2))
-
-
-def _blob_overlap(b1, b2):
-    """skimage.feature.blob._blob_overlap for 2-D blobs [row, col, sigma]."""
-    root2 = math.sqrt(2)
-    if b1[2] == b2[2] == 0:
-        return 0.0
-    if b1[2] > b2[2]:
-        ms, r1, r2 = b1[2], 1.0, b2[2] / b1[2]
-    else:
-        ms, r2, r1 = b2[2], 1.0, b1[2] / b2[2]
-    d = math.sqrt(((b2[0] - b1[0]) / (ms * root2)) ** 2 + ((b2[1] - b1[1]) / (ms * root2)) ** 2)
-    if d > r1 + r2:
-        return 0.0
-    if d <= abs(r1 - r2):
-        return 1.0
-    return _disk_overlap(d, r1, r2)
-
-
 def _prune_blobs(blobs, overlap):
-    """skimage.feature.blob._prune_blobs (scikit-image 0.19.2), pair order included: the candidate pairs come out of
-    cKDTree.query_pairs as a Python set and are visited in that set's iteration order - chains of overlapping blobs
-    make the result order dependent (0-3 blobs per real frame), so the same construct is used here.
-    (The engine's device-side retrack restates the same order natively: csrc/blobprune.h.)"""
-    from scipy import spatial
-    sigma = blobs[:, -1].max()
-    distance = 2 * sigma * math.sqrt(blobs.shape[1] - 1)
-    pairs = np.array(list(spatial.cKDTree(blobs[:, :-1]).query_pairs(distance)))
-    if len(pairs) == 0:
-        return blobs
-    blobs = blobs.copy()
-    for i, j in pairs:
-        b1, b2 = blobs[i], blobs[j]
-        if _blob_overlap(b1, b2) > overlap:
-            if b1[-1] > b2[-1]:
-                b2[-1] = 0
-            else:
-                b1[-1] = 0
-    return blobs[blobs[:, -1] > 0]
+    """skimage.feature.blob._prune_blobs (scikit-image 0.19.2), PAIR ORDER INCLUDED: scikit-image takes the candidate pairs
+    out of cKDTree.query_pairs as a Python set and visits them in that set's iteration order; chains of overlapping
+    blobs make the survivors depend on it (0-3 blobs per real frame, which then reshuffle ~15 % of the ANMS selection).
+    roam_prune_blobs (csrc/blobprune.h) restates cKDTree's emission order and CPython's set order natively; the
+    engine's device-side retrack runs the same code on the GPU."""
+    import ctypes as C
+    bl = np.ascontiguousarray(blobs, np.float64)
+    keep = np.zeros(len(bl), np.uint8)
+    rc = _ffi.load_library().roam_prune_blobs(_ffi._ptr(bl), len(bl), C.c_double(overlap), _ffi._ptr(keep))
+    if rc != _ffi.ROAM_OK:
+        raise _ffi.RoamError(rc, "roam_prune_blobs: %d blobs (integer pixel coordinates, <= 32767 candidate pairs)" % len(bl))
+    return bl[keep.astype(bool)]
 
 
 def argsort_numpy122(keys) -> np.ndarray:
@@ -68,72 +34,12 @@ def argsort_numpy122(keys) -> np.ndarray:
     sort is an introsort (median of three, Hoare partition, insertion sort for runs of <= 17 elements) that is NOT
     stable, and adaptiveNMS sorts ~400 blobs by a sigma that takes two values (getFeatures.py:69) - the order of
     the ties decides which blobs SSC keeps.  NumPy >= 2 uses vectorised sorts with a different tie order."""
-    v = [float(x) for x in keys]
-    n = len(v)
-    t = list(range(n))
-    if n < 2:
-        return np.array(t, np.int64)
-    lo, hi, todo, budget = 0, n - 1, [], 2 * (n.bit_length() - 1)
-    while True:
-        if budget < 0:                                   # depth limit: heap sort of the run (never reached for blob counts)
-            t[lo:hi + 1] = _heap_argsort(v, t[lo:hi + 1])
-        else:
-            while hi - lo > 16:
-                mid = lo + ((hi - lo) >> 1)
-                if v[t[mid]] < v[t[lo]]: t[mid], t[lo] = t[lo], t[mid]
-                if v[t[hi]] < v[t[mid]]: t[hi], t[mid] = t[mid], t[hi]
-                if v[t[mid]] < v[t[lo]]: t[mid], t[lo] = t[lo], t[mid]
-                pivot = v[t[mid]]
-                i, j = lo, hi - 1
-                t[mid], t[j] = t[j], t[mid]
-                while True:
-                    i += 1
-                    while v[t[i]] < pivot: i += 1
-                    j -= 1
-                    while pivot < v[t[j]]: j -= 1
-                    if i >= j:
-                        break
-                    t[i], t[j] = t[j], t[i]
-                t[i], t[hi - 1] = t[hi - 1], t[i]
-                budget -= 1
-                if i - lo < hi - i:                      # the larger part waits, the smaller one is sorted first
-                    todo.append((i + 1, hi, budget)); hi = i - 1
-                else:
-                    todo.append((lo, i - 1, budget)); lo = i + 1
-            for i in range(lo + 1, hi + 1):
-                cur, j = t[i], i
-                while j > lo and v[cur] < v[t[j - 1]]:
-                    t[j] = t[j - 1]; j -= 1
-                t[j] = cur
-        if not todo:
-            break
-        lo, hi, budget = todo.pop()
-    return np.array(t, np.int64)
-
-
-def _heap_argsort(v, idx):
-    a = [None] + list(idx)
-    n = len(idx)
-    for l in range(n >> 1, 0, -1):
-        tmp, i, j = a[l], l, l << 1
-        while j <= n:
-            if j < n and v[a[j]] < v[a[j + 1]]: j += 1
-            if v[tmp] < v[a[j]]:
-                a[i] = a[j]; i = j; j += j
-            else:
-                break
-        a[i] = tmp
-    while n > 1:
-        tmp = a[n]; a[n] = a[1]; n -= 1
-        i, j = 1, 2
-        while j <= n:
-            if j < n and v[a[j]] < v[a[j + 1]]: j += 1
-            if v[tmp] < v[a[j]]:
-                a[i] = a[j]; i = j; j += j
-            else:
-                break
-        a[i] = tmp
-    return a[1:]
+    k = np.ascontiguousarray(keys, np.float64)
+    out = np.empty(max(len(k), 1), np.int32)
+    rc = _ffi.load_library().roam_argsort_np122(_ffi._ptr(k), len(k), _ffi._ptr(out))
+    if rc != _ffi.ROAM_OK:
+        raise _ffi.RoamError(rc, "roam_argsort_np122")
+    return out[:len(k)].astype(np.int64)
 
 
 def getBlobsFromCart(cartImage: np.ndarray, min_sigma=1, max_sigma=30, num_sigma=10, threshold=0.01, method="doh",

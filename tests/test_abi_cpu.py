@@ -143,3 +143,38 @@ def test_trajectory_and_gt_loader(tmp_path):
     assert tr.poses.shape == (4, 3)
     assert abs(computePosesRMSE(np.zeros((3, 3)), np.array([[3, 4, 0.0]] * 3)) - 5.0) < 1e-12
     assert np.allclose(gt.getPoseAtTimes(102), gt.poses[2], atol=1e-9)
+
+
+def test_native_blob_bookkeeping_matches_oracle_and_live_scipy():
+    """roam_prune_blobs / roam_argsort_np122 are host code inside libroam_hip.so (no GPU): the product's restatement of
+    scikit-image's pair order and NumPy 1.22's tie order against the oracle's independent C restatement, and against the
+    skimage construct executed on the live scipy + CPython"""
+    import math
+    import numpy as np
+    import oracle
+    from radarslampy_amd import getFeatures as gf
+    from scipy import spatial
+    from test_oracle_reference_dump import _overlap
+    rng = np.random.default_rng(8)
+    for t in range(30):
+        n = int(rng.integers(1, 900))
+        c = rng.integers(20, 2000, size=(max(1, n // (3 if t % 2 else 12)), 2))
+        b = np.column_stack([np.clip(c[rng.integers(0, len(c), n)] + rng.integers(-18, 19, size=(n, 2)), 0, 2023).astype(float),
+                             rng.choice([5.005, 10.0], size=n)])
+        got = gf._prune_blobs(b, 0.5)
+        assert np.array_equal(got, oracle.prune_blobs(b, 0.5)), t
+        if t < 8:
+            want = b.copy()
+            for i, j in np.array(list(spatial.cKDTree(want[:, :2]).query_pairs(2 * want[:, 2].max() * math.sqrt(2)))).reshape(-1, 2):
+                b1, b2 = want[i], want[j]
+                if _overlap(b1, b2) > 0.5:
+                    if b1[2] > b2[2]:
+                        b2[2] = 0
+                    else:
+                        b1[2] = 0
+            assert np.array_equal(got, want[want[:, 2] > 0]), t
+        v = rng.choice([5.005, 10.0], size=n) if t % 3 else rng.standard_normal(n)
+        assert np.array_equal(gf.argsort_numpy122(v), oracle.argsort_numpy122(v)), t
+    v = np.concatenate([np.arange(3000), np.arange(3000)[::-1]]).astype(float)       # organ pipe: deep recursion
+    assert np.array_equal(gf.argsort_numpy122(v), oracle.argsort_numpy122(v))
+    assert len(gf._prune_blobs(np.zeros((0, 3)), 0.5)) == 0 and len(gf.argsort_numpy122(np.zeros(0))) == 0
