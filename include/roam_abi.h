@@ -160,6 +160,9 @@ typedef struct roam_engine_cfg {
     int32_t motion_distortion;/* 1: LM pose (RawROAMSystem.py:208-237); 0: Kabsch dead reckoning (:236,301-317) */
     int64_t clique_node_limit;
     double sigma5[5];
+    int32_t retrack_on_device;/* 1: lanes that run out of features (<= 60 inliers, RawROAMSystem.py:250-271) re-detect
+                                 (appendNewFeatures: DoH blobs + ANMS, getFeatures.py:74-118) inside roam_engine_step */
+    int32_t retrack_slots;    /* lanes whose detection scratch (37 MB each) is resident at once; 0 = min(lanes, 512) */
 } roam_engine_cfg;
 
 typedef struct roam_lane_result {
@@ -173,8 +176,10 @@ typedef struct roam_lane_result {
     int32_t n_peaks;          /* polar peaks of the current scan                          */
     int32_t lm_nfev;
     int32_t lm_info;
-    int32_t flags;            /* bit0 clique proven, bit1 keyframe added, bit2 retrack wanted */
-    int32_t pad;
+    int32_t flags;            /* bit0 clique proven, bit1 keyframe added, bit2 retrack wanted (features ran out),
+                                 bit3 retrack done on the device in this step; bits 8..11 detection overflows
+                                 (candidates > 2048, k-d tree, pairs > 32767, features > 1024): never set on real scans */
+    int32_t n_after_retrack;  /* feature count after the device-side append (bit3), else 0 */
 } roam_lane_result;
 
 int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg);
@@ -203,6 +208,14 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
 int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx);
 /* blocking: fetch the per-lane results of the last step */
 int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
+/* per-step results without draining the pipeline: every step's records are copied to pinned host memory on a side stream
+ * (ring of the last 8 steps); this call waits for step `step` only (0-based count of roam_engine_step calls) - poses and
+ * flags of step N can be consumed while steps N+1.. are still running.  ROAM_E_STATE if the step left the ring. */
+int32_t roam_engine_step_results(roam_ctx *ctx, int64_t step, roam_lane_result *out, int32_t n);
+int32_t roam_engine_steps_enqueued(roam_ctx *ctx, int64_t *nstep);
+/* like roam_engine_init_lane, but the initial features are DETECTED on the device from the pool scan
+ * (appendNewFeatures(prevImgCart, empty), RawROAMSystem.py:150); needs cfg.retrack_on_device */
+int32_t roam_engine_init_lane_detect(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const double *pose3);
 /* blocking: current feature set of a lane (cap rows), and its peak list */
 int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t lane, float *pts, int32_t cap, int32_t *K);
 int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_t cap, int64_t *n);

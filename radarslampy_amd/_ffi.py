@@ -23,14 +23,15 @@ class EngineCfg(C.Structure):
     _fields_ = [("lanes", C.c_int32), ("rows", C.c_int32), ("stride", C.c_int32), ("payload_off", C.c_int32),
                 ("clip", C.c_int32), ("pool_scans", C.c_int32), ("peaks_cap", C.c_int32),
                 ("reject_outliers", C.c_int32), ("motion_distortion", C.c_int32),
-                ("clique_node_limit", C.c_int64), ("sigma5", C.c_double * 5)]
+                ("clique_node_limit", C.c_int64), ("sigma5", C.c_double * 5), ("retrack_on_device", C.c_int32),
+                ("retrack_slots", C.c_int32)]
 
 
 class LaneResult(C.Structure):
     _fields_ = [("pose", C.c_double * 3), ("velocity", C.c_double * 3), ("kabsch_R", C.c_double * 4),
                 ("kabsch_h", C.c_double * 2), ("n_tracked", C.c_int32), ("n_good", C.c_int32),
                 ("n_inliers", C.c_int32), ("n_peaks", C.c_int32), ("lm_nfev", C.c_int32),
-                ("lm_info", C.c_int32), ("flags", C.c_int32), ("pad", C.c_int32)]
+                ("lm_info", C.c_int32), ("flags", C.c_int32), ("n_after_retrack", C.c_int32)]
 
 
 class KeyframeHdr(C.Structure):
@@ -72,6 +73,9 @@ _SIGS = {
     "roam_engine_init_lane": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp]),
     "roam_engine_step": (C.c_int32, [_vp, _vp]),
     "roam_engine_results": (C.c_int32, [_vp, _P(LaneResult), C.c_int32]),
+    "roam_engine_step_results": (C.c_int32, [_vp, C.c_int64, _P(LaneResult), C.c_int32]),
+    "roam_engine_steps_enqueued": (C.c_int32, [_vp, _P(C.c_int64)]),
+    "roam_engine_init_lane_detect": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp]),
     "roam_engine_lane_features": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_lane_peaks": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
     "roam_engine_doh_maxima": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, C.c_double, _vp, _vp, C.c_int32, _P(C.c_int32)]),

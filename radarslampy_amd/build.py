@@ -25,7 +25,7 @@ def _stale(out, deps):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, "roam_internal.h"), os.path.join(HERE, "..", "include", "roam_abi.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "roam_abi.h")]
     objs, jobs = [], []
     for s in _sources():
         src = os.path.join(CSRC, s)

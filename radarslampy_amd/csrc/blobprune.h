@@ -20,7 +20,7 @@
 
 #if defined(__HIPCC__)
 #define BP_HD __host__ __device__ __forceinline__
-#define BP_HDN __host__ __device__
+#define BP_HDN __host__ __device__ inline
 #else
 #define BP_HD inline
 #define BP_HDN inline

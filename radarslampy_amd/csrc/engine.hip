@@ -17,6 +17,7 @@
 // (Mapping.py:37-66,97-125,149-174).  Scan pairs of different lanes are independent, so the
 // batch dimension is what fills the 256 CUs; within a lane the chain is sequential.
 #include "roam_internal.h"
+#include "retrack.h"
 #include <algorithm>
 #include <new>
 
@@ -29,9 +30,10 @@
 #define ERR_THR 10.0f            // getTransformKLT.py:84
 #define TWO_PI 6.283185307179586476925286766559
 
-enum { ST_PEAKS = 0, ST_WARP, ST_PYR, ST_KLT, ST_GRAPH, ST_CLIQUE, ST_KABSCH, ST_LM, ST_GLUE, ST_COUNT };
+#define RES_RING 8
+enum { ST_PEAKS = 0, ST_WARP, ST_PYR, ST_KLT, ST_GRAPH, ST_CLIQUE, ST_KABSCH, ST_LM, ST_GLUE, ST_RETRACK, ST_COUNT };
 static const char *kStageNames[ST_COUNT] = {"ingest_peaks", "warp_quantise", "pyramid", "klt", "consistency_graph",
-                                            "max_clique", "kabsch", "mds_lm", "glue"};
+                                            "max_clique", "kabsch", "mds_lm", "glue", "retrack"};
 
 struct Engine {
     roam_engine_cfg cfg;
@@ -73,7 +75,14 @@ struct Engine {
     double *T_wj0 = nullptr, *T_init = nullptr, *p_w = nullptr, *p_jt = nullptr;
     double *lm_work = nullptr, *lm_out = nullptr;
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
-    roam_lane_result *results = nullptr;
+    roam_lane_result *results = nullptr;           // ring of RES_RING per-step records (RES_RING x B)
+    roam_lane_result *results_host = nullptr;      // pinned mirror, filled asynchronously after every step
+    hipEvent_t ev_res[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_resrdy = nullptr, ev_pool = nullptr;
+    hipStream_t s_res = nullptr;                    // asynchronous D2H of the per-step result records
+    bool pool_dirty = false;
+    RtArgs rt;                                      // device-side retrack (retrack.hip)
+    bool rt_on = false;
     uint8_t *kfb = nullptr;                         // 8e: packed keyframe payload (RCCL broadcast buffer)
     hipEvent_t ev[ST_COUNT + 1];
     hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
@@ -87,7 +96,8 @@ struct Engine {
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
-    int kmax() const { int m = 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
+    // device-side retracks grow a lane to at most 60 + 220 features without the host knowing which lane
+    int kmax() const { int m = rt_on ? 320 : 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
     std::vector<void *> allocs;
 };
 
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
         r->lm_nfev = (n >= 2 && cfg.motion_distortion) ? lm_nfev[b] : 0;
         r->lm_info = (n >= 2 && cfg.motion_distortion) ? lm_info[b] : 0;
         r->flags = (cq_flags[b] & 1) | (newkf ? 2 : 0) | (retrack ? 4 : 0);
-        r->pad = 0;
+        r->n_after_retrack = 0;
     }
     __syncthreads();
     const double v0 = nv_[0], v1 = nv_[1], v2 = nv_[2];
@@ -414,6 +424,11 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
                     for (int i = 0; i < 4; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } hipEventDestroy(e->ev_warp); hipEventDestroy(e->ev_idx); hipEventDestroy(e->ev_peaks); }
     if (e->scan_host) hipHostFree(e->scan_host);
+    if (e->results_host) hipHostFree(e->results_host);
+    for (auto &ev : e->ev_res) if (ev) hipEventDestroy(ev);
+    if (e->ev_resrdy) hipEventDestroy(e->ev_resrdy);
+    if (e->ev_pool) hipEventDestroy(e->ev_pool);
+    if (e->s_res) { hipStreamSynchronize(e->s_res); hipStreamDestroy(e->s_res); }
     if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
@@ -493,8 +508,43 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->lm_out, (size_t)B * 6);
     ok = ok && dalloc(ctx, e, &e->lm_nfev, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->lm_info, (size_t)B);
-    ok = ok && dalloc(ctx, e, &e->results, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->results, (size_t)B * RES_RING);
+    if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->results_host), sizeof(roam_lane_result) * (size_t)B * RES_RING, hipHostMallocDefault) != hipSuccess) {
+        ROAM_SET_ERR(ctx, "engine: hipHostMalloc failed"); ok = false;
+    }
+    e->rt_on = cfg->retrack_on_device != 0;
+    if (ok && e->rt_on) {
+        // device-side feature (re)detection: DEFAULT_FEATURE_PARAMS of getFeatures.py:13-18, i.e. sigma = linspace(0.01, 10, 3)
+        RtArgs &r = e->rt;
+        memset(&r, 0, sizeof(r));
+        const double step = (10.0 - 0.01) / 2.0;                         // numpy.linspace: arange(num) * step + start, last = stop
+        r.sigma1 = 1.0 * step + 0.01; r.sigma2 = 10.0; r.threshold = 0.0005;
+        r.size1 = (int)(3 * r.sigma1); r.size2 = (int)(3 * r.sigma2);
+        r.W = e->W; r.rows = cfg->rows; r.cols = cfg->clip; r.stride = cfg->stride; r.payload_off = cfg->payload_off;
+        r.rec_bytes = (int64_t)e->rec_bytes;
+        const int R = r.slots = std::max(1, std::min(B, cfg->retrack_slots > 0 ? cfg->retrack_slots : 512));
+        const size_t npx = (size_t)e->W * e->W;
+        if (e->W > 2048) { ROAM_SET_ERR(ctx, "engine: device retrack needs a Cartesian image of at most 2048 x 2048"); roam_engine_destroy(ctx); return ROAM_E_ARG; }
+        ok = ok && dalloc(ctx, e, &r.rt_n, 1) && dalloc(ctx, e, &r.rt_lane, (size_t)B) && dalloc(ctx, e, &r.rt_scan, (size_t)B);
+        ok = ok && dalloc(ctx, e, &r.S, npx * R) && dalloc(ctx, e, &r.mask, npx * R) && dalloc(ctx, e, &r.row_cnt, (size_t)R * (e->W + 1));
+        ok = ok && dalloc(ctx, e, &r.cand_rc, (size_t)R * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_val, (size_t)R * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_n, (size_t)R);
+        ok = ok && dalloc(ctx, e, &r.tasks, (size_t)R * BP_MAX_TASKS) && dalloc(ctx, e, &r.pairs, (size_t)R * (BP_MAX_PAIRS + 1));
+        ok = ok && dalloc(ctx, e, &r.order, (size_t)R * (BP_MAX_PAIRS + 1)) && dalloc(ctx, e, &r.ovbits, (size_t)R * ((BP_MAX_PAIRS + 31) / 32 + 1));
+        ok = ok && dalloc(ctx, e, &r.bigtab, (size_t)R * 2 * 131072);
+        ok = ok && dalloc(ctx, e, &r.kp, (size_t)R * BP_MAX_PTS * 3) && dalloc(ctx, e, &r.kp_n, (size_t)R) && dalloc(ctx, e, &r.slot_flags, (size_t)R);
+        ok = ok && dalloc(ctx, e, &r.ssc_work, (size_t)R * 4 * BP_MAX_PTS) && dalloc(ctx, e, &r.sel, (size_t)R * BP_MAX_PTS) && dalloc(ctx, e, &r.sel_n, (size_t)R);
+    }
     if (!ok) { roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    if (e->rt_on) {
+        RtArgs &r = e->rt;
+        r.pool = e->pool; r.map = e->warp_map; r.feat = e->feat; r.feat_n = e->feat_n; r.vel = e->vel; r.kf_und = e->kf_und; r.res = nullptr;
+    }
+    for (auto &ev : e->ev_res)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    if (hipEventCreateWithFlags(&e->ev_resrdy, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_pool, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->s_res, hipStreamNonBlocking) != hipSuccess) {
+        ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
+    }
     for (auto &ev : e->ev) {
         if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     }
@@ -563,8 +613,12 @@ int32_t roam_engine_copy_scan(roam_ctx *ctx, int32_t dst_idx, int32_t src_idx)
     ENGINE();
     ARG_CHECK(ctx, dst_idx >= 0 && dst_idx < e->cfg.pool_scans && src_idx >= 0 && src_idx < e->cfg.pool_scans);
     if (dst_idx != src_idx)
+    {
         HIP_TRY(ctx, hipMemcpyAsync(e->pool + (size_t)dst_idx * e->rec_bytes, e->pool + (size_t)src_idx * e->rec_bytes,
                                     e->rec_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(e->ev_pool, ctx->stream));         // the front-end streams of the next step wait for it
+        e->pool_dirty = true;
+    }
     return ROAM_OK;
 }
 
@@ -677,6 +731,7 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
 {
     ENGINE();
     ARG_CHECK(ctx, lane >= 0 && lane < e->B && pool_idx >= 0 && pool_idx < e->cfg.pool_scans && pose3 && K >= 0 && K <= KS);
+    if (e->uploads_pending) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up, 0));     // asynchronous uploads land first
     // previous-image pyramid of this lane from the pool scan
     uint8_t *pyr = e->pyr[e->cur] + (size_t)lane * e->pd.lane_stride;
     WarpSrc ws = {e->pool + (size_t)pool_idx * e->rec_bytes, 0, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, nullptr};
@@ -687,6 +742,26 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
     HIP_TRY(ctx, hipMemcpyAsync(e->vel + 3 * (size_t)lane, zero, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return set_features_impl(ctx, e, lane, pts, K, pool_idx);
+}
+
+int32_t roam_engine_init_lane_detect(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const double *pose3)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B && pool_idx >= 0 && pool_idx < e->cfg.pool_scans && pose3);
+    if (!e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
+    int32_t rc = roam_engine_init_lane(ctx, lane, pool_idx, nullptr, 0, pose3);      // pyramid, pose, zero velocity, empty keyframe
+    if (rc != ROAM_OK) return rc;
+    // first-frame appendNewFeatures(prevImgCart, empty) (RawROAMSystem.py:150): the retrack path for this one lane
+    const int32_t one = 1;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_n, &one, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_lane, &lane, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_scan, &pool_idx, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    e->rt.res = nullptr;
+    HIP_TRY(ctx, launch_retrack(st, e->rt, 1));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    e->lane_k[lane] = 320;
+    return ROAM_OK;
 }
 
 int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyframe_hdr *hdr_out, double *locals_xy,
@@ -749,6 +824,9 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     //   A(N) waits for g4(N-3)   - that kernel reads the peak counts / scan indices of the same ring slot
     //   B(N) waits for A(N), KLT(N) waits for B(N)
     hipStream_t sA = ctx->stream2, sB = ctx->stream4;
+    const int rs = (int)(e->nstep % RES_RING);            // ring slot of this step's result records
+    if (e->nstep >= RES_RING) HIP_TRY(ctx, hipEventSynchronize(e->ev_res[rs]));   // its previous copy (8 steps ago) has long landed
+    roam_lane_result *res_slot = e->results + (size_t)rs * B;
     const int pb = (int)(e->nstep % 3);                 // ring slot of the peak / scan-index buffers
     const int k4 = (int)(e->nstep & 3), w4 = (int)((e->nstep + 1) & 3);   // event slot of this step / of step N-3
     uint8_t *prev = e->pyr[e->cur], *next = e->pyr[(e->cur + 1) & 3];
@@ -756,6 +834,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_g4[w4], 0));
     // (lane initialisation, retracks and synchronous uploads finish on the host before a step is enqueued)
     if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(sA, ctx->ev_up, 0)); e->uploads_pending = false; }
+    if (e->pool_dirty) { HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_pool, 0)); e->pool_dirty = false; }   // device-to-device record copies
     int32_t *hs = e->scan_host + (size_t)pb * B;
     if (e->nstep >= 3) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[w4]));   // the staging slot's last copy has long been consumed
     for (int b = 0; b < B; b++) hs[b] = scan_idx[b];
@@ -818,11 +897,23 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_peaks, 0));
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
                        e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n[pb],
-                       e->cq_flags, e->results, e->scan_idx[pb], e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
+                       e->cq_flags, res_slot, e->scan_idx[pb], e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
                        e->map_cap);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e->ev[ST_RETRACK], st));
+    if (e->rt_on) {
+        // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
+        e->rt.res = res_slot;
+        HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B));
+    }
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
     HIP_TRY(ctx, hipEventRecord(e->ev_g4[k4], st));
+    // per-step result record -> pinned host ring, off the compute stream: roam_engine_step_results(step) waits for THIS copy only
+    HIP_TRY(ctx, hipEventRecord(e->ev_resrdy, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(e->s_res, e->ev_resrdy, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(e->results_host + (size_t)rs * B, res_slot, sizeof(roam_lane_result) * (size_t)B, hipMemcpyDeviceToHost, e->s_res));
+    HIP_TRY(ctx, hipEventRecord(e->ev_res[rs], e->s_res));
     e->cur = (e->cur + 1) & 3;
     e->pk = pb;
     e->nstep++;
@@ -834,8 +925,30 @@ int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n)
 {
     ENGINE();
     ARG_CHECK(ctx, out && n >= 1 && n <= e->B);
-    HIP_TRY(ctx, hipMemcpyAsync(out, e->results, sizeof(roam_lane_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e->nstep == 0) { ROAM_SET_ERR(ctx, "no step enqueued"); return ROAM_E_STATE; }
+    return roam_engine_step_results(ctx, e->nstep - 1, out, n);
+}
+
+int32_t roam_engine_step_results(roam_ctx *ctx, int64_t step, roam_lane_result *out, int32_t n)
+{
+    ENGINE();
+    ARG_CHECK(ctx, out && n >= 1 && n <= e->B);
+    if (step < 0 || step >= e->nstep || step < e->nstep - RES_RING) {
+        ROAM_SET_ERR(ctx, "step %lld is not in the result ring (steps %lld..%lld)", (long long)step,
+                     (long long)std::max<int64_t>(0, e->nstep - RES_RING), (long long)e->nstep - 1);
+        return ROAM_E_STATE;
+    }
+    const int rs = (int)(step % RES_RING);
+    HIP_TRY(ctx, hipEventSynchronize(e->ev_res[rs]));      // waits for that step's records only; later steps keep running
+    memcpy(out, e->results_host + (size_t)rs * e->B, sizeof(roam_lane_result) * (size_t)n);
+    return ROAM_OK;
+}
+
+int32_t roam_engine_steps_enqueued(roam_ctx *ctx, int64_t *nstep)
+{
+    ENGINE();
+    ARG_CHECK(ctx, nstep);
+    *nstep = e->nstep;
     return ROAM_OK;
 }
 

@@ -1,0 +1,46 @@
+// retrack.h - arguments of the device-side feature (re)detection (retrack.hip), filled by the engine
+#pragma once
+#include "roam_internal.h"
+#include "blobprune.h"
+
+enum { RT_F_CAND_OVERFLOW = 1, RT_F_TREE_OVERFLOW = 2, RT_F_PAIR_OVERFLOW = 4, RT_F_FEAT_OVERFLOW = 8 };
+
+struct RtArgs {
+    // geometry / parameters
+    int W, rows, cols, stride, payload_off, slots, size1, size2;
+    int64_t rec_bytes;
+    double sigma1, sigma2, threshold;
+    // engine state
+    const uint8_t *pool;
+    const uint32_t *map;
+    float *feat;
+    int32_t *feat_n;
+    const double *vel;
+    double *kf_und;
+    roam_lane_result *res;          // result records of the step being amended (may be null)
+    // flagged lanes (device-built): rt_n lanes, lane / pool scan of each
+    int32_t *rt_n, *rt_lane, *rt_scan;
+    // per-slot scratch (slots entries each)
+    double *S;                      // W x W float64 integral image
+    uint8_t *mask;                  // W x W: bit s = 3x3x3 maximum in layer s
+    int32_t *row_cnt;               // W + 1
+    uint32_t *cand_rc;              // BP_MAX_PTS: row << 16 | col << 2 | layer
+    double *cand_val;               // BP_MAX_PTS
+    int32_t *cand_n;
+    BpTask *tasks;                  // BP_MAX_TASKS
+    uint32_t *pairs;                // BP_MAX_PAIRS + 1
+    uint16_t *order;                // BP_MAX_PAIRS + 1
+    uint32_t *ovbits;               // (BP_MAX_PAIRS + 31) / 32 + 1
+    uint16_t *bigtab;               // 2 x 131072 (set tables of the rare > 4914-pair case)
+    double *kp;                     // BP_MAX_PTS x 3 keypoints in adaptiveNMS priority order
+    int32_t *kp_n, *slot_flags;
+    int32_t *ssc_work;              // 4 x BP_MAX_PTS
+    int32_t *sel, *sel_n;           // BP_MAX_PTS, 1
+};
+
+hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, const RtArgs &a);
+// runs the detection for the rt_n flagged lanes (device count, at most B), in chunks of a.slots
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B);
+hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride, const int32_t *count, int kp_cap, int P,
+                            int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
+                            const int32_t *n_active, int first);

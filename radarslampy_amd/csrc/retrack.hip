@@ -1,0 +1,452 @@
+// Device-side feature (re)detection of the engine: appendNewFeatures(currImgCart, good_new) of the reference's loop
+// (RawROAMSystem.py:250-271, getFeatures.py:74-118) for every lane whose step ran out of features, inside
+// roam_engine_step, without a host round trip.  Per flagged lane ("slot"):
+//   K1 rt_integ_cols   float32 Cartesian pixel from the polar record through the engine's sampling map (the arithmetic of
+//                      warp.hip, never written to memory) and the column cumsum of the float64 integral image
+//   K2 rt_integ_rows   row cumsum (sequential order per row, 64 x 64 LDS transpose tiles)
+//   K3 rt_det_mask     box-filter Hessian determinants of both live layers (sigma 5.005 / 10, sizes 15 / 30; the
+//                      sigma 0.01 layer is all-NaN in scikit-image and ignored) on a 16 x 64 tile + halo in LDS, 3x3x3
+//                      maxima above the threshold -> one byte per pixel (bit s = maximum in layer s) + per-row counts
+//   K4 rt_emit         row offsets (scan) and the candidates in C (row, col, layer) order with their responses
+//   K5 rt_blobs        one wavefront per lane: response order, scikit-image's _prune_blobs in ITS pair order (blobprune.h:
+//                      cKDTree emission order + CPython set order; sequential parts on lane 0 out of LDS), NumPy-1.22
+//                      argsort of the sigmas -> keypoints in adaptiveNMS's priority order
+//   K6 ssc_batch       ANMS.ssc (ssc.hip)
+//   K7 rt_append       [x, y] flip, vstack + drop exact duplicates keeping the first (getFeatures.py:109-112), keyframe
+//                      refresh (Mapping.py:59-66 with the frame's velocity), feature count
+// Slots are processed in chunks of `slots` lanes (scratch: 37 MB per slot); every kernel exits at once for slots beyond
+// the number of flagged lanes, which only the device knows.
+#include "roam_internal.h"
+#include "doh_common.h"
+#include "blobprune.h"
+#include "retrack.h"
+
+#define KS ROAM_MAX_FEATURES
+#define CART_CENTER 1012.0
+#define M_PER_PX 0.0864
+#define TWO_PI 6.283185307179586476925286766559
+
+// ------------------------------------------------------------------------------------------------ K0: flagged lanes
+__global__ __launch_bounds__(256) void rt_collect_kernel(const roam_lane_result *__restrict__ res, const int32_t *__restrict__ scan_idx,
+                                                         int B, int32_t *__restrict__ rt_lane, int32_t *__restrict__ rt_scan,
+                                                         int32_t *__restrict__ rt_n)
+{
+    __shared__ int sh[8];
+    __shared__ int base_s;
+    const int t = threadIdx.x;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + t;
+        const int f = (b < B && (res[b].flags & 4)) ? 1 : 0;
+        // block exclusive scan
+        const int lane = t & 63, w = t >> 6;
+        int inc = f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int n = __shfl_up(inc, d); if (lane >= d) inc += n; }
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        int off = base_s, tot = 0;
+        for (int i = 0; i < 4; i++) { if (i < w) off += sh[i]; tot += sh[i]; }
+        if (f) { rt_lane[off + inc - 1] = b; rt_scan[off + inc - 1] = scan_idx[b]; }
+        __syncthreads();
+        if (t == 0) base_s += tot;
+        __syncthreads();
+    }
+    if (t == 0) *rt_n = base_s;
+}
+
+// ------------------------------------------------------------------------------------------------ K1 / K2: integral image
+__device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dmul_rn((double)k, 1.0 / 255.0); }
+
+__global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
+{
+    const int ls = blockIdx.y, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, W = a.W;
+    if (c >= W) return;
+    const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
+    double *S = a.S + (int64_t)ls * W * W;
+    const int rows = a.rows, cols = a.cols, stride = a.stride;
+    double acc = 0;
+    for (int r = 0; r < W; r++) {
+        const uint32_t m = a.map[(int64_t)r * W + c];
+        const int ix = m & 4095, iy = (m >> 12) & 1023;
+        float v = 0.f;
+        if (ix < cols) {                                 // the arithmetic of warp_gather_kernel's direct path (= warp_pixel)
+            const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+            const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+            int r0 = iy - 1, r1 = iy;
+            if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
+            if (r1 >= rows) r1 -= rows;
+            const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
+            const bool i1 = ix + 1 < cols;
+            const float s00 = rt_code_to_f32(q0[0]), s01 = i1 ? rt_code_to_f32(q0[1]) : 0.f;
+            const float s10 = rt_code_to_f32(q1[0]), s11 = i1 ? rt_code_to_f32(q1[1]) : 0.f;
+            v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
+            v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
+            v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
+            v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
+        }
+        acc = __dadd_rn(acc, (double)v);
+        S[(int64_t)r * W + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
+{
+    __shared__ double tile[64][65];
+    const int ls = blockIdx.y, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    const int W = a.W, H = a.W;
+    double *S = a.S + (int64_t)ls * W * W;
+    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+    double acc = 0;
+    for (int c0 = 0; c0 < W; c0 += 64) {
+        for (int k = 0; k < 64; k++) {
+            const int r = r0 + k, c = c0 + lane;
+            tile[k][lane] = (r < H && c < W) ? S[(int64_t)r * W + c] : 0.0;
+        }
+        __syncthreads();
+        const int nc = min(64, W - c0);
+        for (int j = 0; j < nc; j++) { acc = __dadd_rn(acc, tile[lane][j]); tile[lane][j] = acc; }
+        __syncthreads();
+        for (int k = 0; k < 64; k++) {
+            const int r = r0 + k, c = c0 + lane;
+            if (r < H && c < W) S[(int64_t)r * W + c] = tile[k][lane];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3: determinants + maxima
+#define RT_TH 16
+#define RT_TW 64
+__global__ __launch_bounds__(256) void rt_det_mask_kernel(RtArgs a, int first)
+{
+    __shared__ double det[2][RT_TH + 2][RT_TW + 2];
+    const int ls = blockIdx.z, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    const int W = a.W, H = a.W;
+    const double *S = a.S + (int64_t)ls * W * W;
+    const int r0 = blockIdx.y * RT_TH, c0 = blockIdx.x * RT_TW, t = threadIdx.x;
+    // outside the image the 3x3x3 footprint sees nothing that could exceed v (mode = 'constant', 0 < threshold < v)
+    for (int i = t; i < 2 * (RT_TH + 2) * (RT_TW + 2); i += 256) {
+        const int l = i / ((RT_TH + 2) * (RT_TW + 2)), rem = i - l * ((RT_TH + 2) * (RT_TW + 2));
+        const int rr = rem / (RT_TW + 2), cc = rem - rr * (RT_TW + 2);
+        const int r = r0 + rr - 1, c = c0 + cc - 1;
+        double v = 0.0;
+        if (r >= 0 && r < H && c >= 0 && c < W) v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
+        det[l][rr][cc] = v;
+    }
+    __syncthreads();
+    const int cc = t & 63, rb = t >> 6;
+    for (int k = 0; k < RT_TH / 4; k++) {
+        const int rr = rb * (RT_TH / 4) + k, r = r0 + rr, c = c0 + cc;
+        if (r >= H || c >= W) continue;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            const double v = det[l][rr + 1][cc + 1];
+            if (!(v > a.threshold)) continue;
+            bool ok = true;
+#pragma unroll
+            for (int ll = 0; ll < 2; ll++)
+#pragma unroll
+                for (int dr = 0; dr < 3; dr++)
+#pragma unroll
+                    for (int dc = 0; dc < 3; dc++) ok = ok && !(det[ll][rr + dr][cc + dc] > v);
+            if (ok) bits |= 1u << l;
+        }
+        a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
+        if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4: ordered candidates
+__global__ __launch_bounds__(256) void rt_emit_kernel(RtArgs a, int first)
+{
+    __shared__ int sh[8];
+    __shared__ int row_off[2048 + 8];
+    const int ls = blockIdx.x, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    const int W = a.W, H = a.W, t = threadIdx.x;
+    const int32_t *rc = a.row_cnt + (int64_t)ls * (W + 1);
+    // exclusive scan of the H row counts (H <= 2048)
+    const int items = (H + 255) / 256, lo = t * items, hi = min(lo + items, H);
+    int c = 0;
+    for (int r = lo; r < hi; r++) c += rc[r];
+    const int lane = t & 63, w = t >> 6;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int n = __shfl_up(inc, d); if (lane >= d) inc += n; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int pos = inc - c, total = 0;
+    for (int i = 0; i < 4; i++) { if (i < w) pos += sh[i]; total += sh[i]; }
+    for (int r = lo; r < hi; r++) { row_off[r] = pos; pos += rc[r]; }
+    __syncthreads();
+    if (t == 0) a.cand_n[ls] = total;
+    const double *S = a.S + (int64_t)ls * W * W;
+    const uint8_t *mk = a.mask + (int64_t)ls * W * W;
+    uint32_t *crc = a.cand_rc + (int64_t)ls * BP_MAX_PTS;
+    double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
+    // rows with maxima: wave w takes rows w, w+4, ...; a lane owns 32 consecutive pixels, order = (col, layer) ascending
+    for (int r = w; r < H; r += 4) {
+        if (rc[r] == 0) continue;
+        const int cb = lane * 32;
+        int cnt = 0;
+        uint32_t m0 = 0, m1 = 0;                            // bit k: pixel cb + k has a maximum in layer 0 / 1
+        for (int k = 0; k < 32; k++) {
+            const int cc = cb + k;
+            const uint32_t b = cc < W ? mk[(int64_t)r * W + cc] : 0;
+            m0 |= (b & 1u) << k; m1 |= ((b >> 1) & 1u) << k;
+        }
+        cnt = __popc(m0) + __popc(m1);
+        int pre = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int n = __shfl_up(pre, d); if (lane >= d) pre += n; }
+        int o = row_off[r] + pre - cnt;
+        for (int k = 0; k < 32; k++)
+            for (int l = 0; l < 2; l++)
+                if (((l ? m1 : m0) >> k) & 1u) {
+                    if (o < BP_MAX_PTS) {
+                        crc[o] = ((uint32_t)r << 16) | ((uint32_t)(cb + k) << 2) | (uint32_t)(l + 1);
+                        cval[o] = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, cb + k);
+                    }
+                    o++;
+                }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5: blob bookkeeping
+struct RtBlobLds {
+    int16_t xy[2 * BP_MAX_PTS];       // [row, col] in response order
+    int16_t idx[BP_MAX_PTS];          // cKDTree.indices, later the aquicksort permutation
+    uint8_t lay[BP_MAX_PTS];          // layer (1 | 2) in response order; 0 = pruned
+    BpNode nodes[BP_MAX_NODES];
+    int st[3 * 256];
+    int bstack[3 * 64];
+    BpTracker tr;
+    uint16_t tabA[2048], tabB[8192];
+    uint32_t ovbits[(BP_LDS_PAIRS + 31) / 32 + 1];
+    int vals[8];
+};
+
+__global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
+{
+    __shared__ RtBlobLds L;
+    const int ls = blockIdx.x, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    const int lane = threadIdx.x;
+    const int ncand = a.cand_n[ls];
+    const int n = min(ncand, BP_MAX_PTS);
+    const uint32_t *crc = a.cand_rc + (int64_t)ls * BP_MAX_PTS;
+    const double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
+    double *kp = a.kp + (int64_t)ls * BP_MAX_PTS * 3;
+    int flags = ncand > BP_MAX_PTS ? RT_F_CAND_OVERFLOW : 0;
+    // 1. response order: peak_local_max sorts by -intensity; equal responses keep the C (row, col, layer) order
+    for (int i = lane; i < n; i += 64) {
+        const double vi = cval[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) { const double vj = cval[j]; rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0; }
+        const uint32_t p = crc[i];
+        L.xy[2 * rank] = (int16_t)(p >> 16); L.xy[2 * rank + 1] = (int16_t)((p >> 2) & 0x3fff); L.lay[rank] = (uint8_t)(p & 3);
+    }
+    __syncthreads();
+    // 2. cKDTree + dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
+    BpTask *tasks = a.tasks + (int64_t)ls * BP_MAX_TASKS;
+    if (lane == 0) {
+        int nn = n > 0 ? bp_build(L.xy, n, L.idx, L.nodes, BP_MAX_NODES, L.bstack) : 0;
+        int nt = 0;
+        if (nn < 0) flags |= RT_F_TREE_OVERFLOW;
+        else if (n > 1) {
+            const double smax = a.sigma2;                    // _prune_blobs: distance = 2 * max sigma * sqrt(2)
+            bool any2 = false;
+            for (int i = 0; i < n; i++) any2 = any2 || L.lay[i] == 2;
+            nt = bp_tasks(L.xy, n, L.nodes, 2 * (any2 ? smax : a.sigma1) * 1.4142135623730951, tasks, BP_MAX_TASKS, L.st, 256, L.tr);
+            if (nt < 0) { flags |= RT_F_TREE_OVERFLOW; nt = 0; }
+        }
+        L.vals[0] = nt; L.vals[1] = flags;
+    }
+    __syncthreads();
+    const int nt = L.vals[0];
+    flags = L.vals[1];
+    // 3. the pairs of the blocks in emission order (i-major, j ascending), 64 candidates per ballot
+    uint32_t *pairs = a.pairs + (int64_t)ls * (BP_MAX_PAIRS + 1);
+    const double ub = L.tr.ub;
+    int np = 0;
+    for (int t = 0; t < nt; t++) {
+        const BpTask tk = tasks[t];
+        const BpNode n1 = L.nodes[tk.a], n2 = L.nodes[tk.b];
+        const int la = n1.end - n1.start, lb = n2.end - n2.start, tot = la * lb;
+        const bool same = tk.a == tk.b;
+        for (int base = 0; base < tot; base += 64) {
+            const int k = base + lane;
+            bool ok = k < tot;
+            int pi = 0, pj = 0;
+            if (ok) {
+                const int i = n1.start + k / lb, j = n2.start + k % lb;
+                if (same && j <= i) ok = false;
+                else {
+                    pi = L.idx[i]; pj = L.idx[j];
+                    if (!tk.mode) {
+                        const double d0 = (double)L.xy[2 * pi] - (double)L.xy[2 * pj], d1 = (double)L.xy[2 * pi + 1] - (double)L.xy[2 * pj + 1];
+                        ok = d0 * d0 + d1 * d1 <= ub;
+                    }
+                }
+            }
+            const uint64_t bal = __ballot(ok);
+            const int o = np + __popcll(bal & ((1ull << lane) - 1ull));
+            if (ok && o < BP_MAX_PAIRS) pairs[o] = bp_pack(pi, pj);
+            np += __popcll(bal);
+        }
+    }
+    if (np > BP_MAX_PAIRS) { flags |= RT_F_PAIR_OVERFLOW; np = BP_MAX_PAIRS; }
+    __syncthreads();
+    // 4. which pairs overlap by more than 0.5 (original sigmas: a pair with a pruned member never changes anything)
+    const bool lds_set = np <= BP_LDS_PAIRS;
+    uint32_t *ovb = lds_set ? L.ovbits : a.ovbits + (int64_t)ls * ((BP_MAX_PAIRS + 31) / 32 + 1);
+    for (int w0 = 0; w0 < np; w0 += 64) {
+        const int k = w0 + lane;
+        bool ov = false;
+        if (k < np) {
+            const uint32_t pr = pairs[k];
+            const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
+            ov = bp_overlaps((double)L.xy[2 * i], (double)L.xy[2 * i + 1], L.lay[i] == 2 ? a.sigma2 : a.sigma1,
+                             (double)L.xy[2 * j], (double)L.xy[2 * j + 1], L.lay[j] == 2 ? a.sigma2 : a.sigma1, 0.5);
+        }
+        const uint64_t bal = __ballot(ov);
+        if (lane == 0) { ovb[w0 >> 5] = (uint32_t)bal; ovb[(w0 >> 5) + 1] = (uint32_t)(bal >> 32); }
+    }
+    __syncthreads();
+    // 5. Python-set iteration order of the pairs + the sequential pruning pass, then 6. NumPy-1.22 argsort of the sigmas
+    uint16_t *order = a.order + (int64_t)ls * (BP_MAX_PAIRS + 1);
+    if (lane == 0) {
+        int m;
+        if (lds_set) m = bp_pyset_order(pairs, np, L.tabA, 2048, L.tabB, 8192, order);
+        else {
+            uint16_t *big = a.bigtab + (int64_t)ls * 2 * 131072;
+            m = bp_pyset_order(pairs, np, big, 131072, big + 131072, 131072, order);
+        }
+        if (m != np) flags |= RT_F_PAIR_OVERFLOW;
+        for (int k = 0; k < (m < 0 ? 0 : m); k++) {
+            const int q = order[k];
+            if (!((ovb[q >> 5] >> (q & 31)) & 1u)) continue;
+            const uint32_t pr = pairs[q];
+            const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
+            if (L.lay[i] == 0 || L.lay[j] == 0) continue;
+            if (L.lay[i] > L.lay[j]) L.lay[j] = 0; else L.lay[i] = 0;     // sigma_i > sigma_j ? prune j : prune i (ties: i)
+        }
+        // survivors in response order (reuse xy / lay in place), sorted by sigma with NumPy 1.22's tie order
+        int mb = 0;
+        for (int i = 0; i < n; i++)
+            if (L.lay[i]) { L.xy[2 * mb] = L.xy[2 * i]; L.xy[2 * mb + 1] = L.xy[2 * i + 1]; L.lay[mb] = L.lay[i]; mb++; }
+        bp_aquicksort(L.lay, mb, L.idx);
+        L.vals[0] = mb; L.vals[1] = flags;
+    }
+    __syncthreads();
+    const int mb = L.vals[0];
+    for (int q = lane; q < mb; q += 64) {
+        const int i = L.idx[q];
+        kp[3 * q] = (double)L.xy[2 * i]; kp[3 * q + 1] = (double)L.xy[2 * i + 1]; kp[3 * q + 2] = L.lay[i] == 2 ? a.sigma2 : a.sigma1;
+    }
+    if (lane == 0) { a.kp_n[ls] = mb; a.slot_flags[ls] = L.vals[1]; }
+}
+
+// ------------------------------------------------------------------------------------------------ K7: append + keyframe refresh
+__global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
+{
+    __shared__ float nx[KS + 256], ny[KS + 256];
+    __shared__ uint8_t keep[KS + 256];
+    __shared__ int sh[8];
+    const int ls = blockIdx.x, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    const int b = a.rt_lane[slot], t = threadIdx.x;
+    float *feat = a.feat + (int64_t)b * KS * 2;
+    const int n_old = min(a.feat_n[b], KS);
+    const int n_sel = min(a.sel_n[ls], 256);
+    const double *kp = a.kp + (int64_t)ls * BP_MAX_PTS * 3;
+    const int32_t *sel = a.sel + (int64_t)ls * BP_MAX_PTS;
+    // vstack((old, fliplr(new[:, :2])))  (getFeatures.py:101-109)
+    for (int i = t; i < n_old; i += 256) { nx[i] = feat[2 * i]; ny[i] = feat[2 * i + 1]; }
+    for (int i = t; i < n_sel; i += 256) { const int q = sel[i]; nx[n_old + i] = (float)kp[3 * q + 1]; ny[n_old + i] = (float)kp[3 * q]; }
+    __syncthreads();
+    const int tot = n_old + n_sel;
+    // np.unique(axis=0, return_index) + sort(idx): drop a row when an earlier row is identical
+    for (int i = t; i < tot; i += 256) {
+        bool dup = false;
+        for (int j = 0; j < i && !dup; j++) dup = nx[j] == nx[i] && ny[j] == ny[i];
+        keep[i] = dup ? 0 : 1;
+    }
+    __syncthreads();
+    // ordered compaction (tot <= KS + 256 -> 5 items per thread)
+    const int items = (KS + 256 + 255) / 256, lo = t * items, hi = min(lo + items, tot);
+    int c = 0;
+    for (int i = lo; i < hi; i++) c += keep[i];
+    const int lane = t & 63, w = t >> 6;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int n = __shfl_up(inc, d); if (lane >= d) inc += n; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int pos = inc - c, total = 0;
+    for (int i = 0; i < 4; i++) { if (i < w) pos += sh[i]; total += sh[i]; }
+    const int m = min(total, KS);
+    const double v0 = a.vel[3 * b], v1 = a.vel[3 * b + 1], v2 = a.vel[3 * b + 2];
+    double *und = a.kf_und + (int64_t)b * KS * 2;
+    for (int i = lo; i < hi; i++)
+        if (keep[i]) {
+            if (pos < KS) {
+                feat[2 * pos] = nx[i]; feat[2 * pos + 1] = ny[i];
+                // possible_kf.updateInfo(latestPose, centered_new, ..., velocity): undistort (Mapping.py:59-66)
+                const double x = ((double)nx[i] - CART_CENTER) * M_PER_PX, y = ((double)ny[i] - CART_CENTER) * M_PER_PX;
+                const double dT = 0.25 * atan2(-y, -x) / TWO_PI;
+                const double ang = v2 * dT, ca = cos(ang), sa = sin(ang);
+                und[2 * pos] = ca * x - sa * y + v0 * dT;
+                und[2 * pos + 1] = sa * x + ca * y + v1 * dT;
+            }
+            pos++;
+        }
+    if (t == 0) {
+        a.feat_n[b] = m;
+        if (a.res) {
+            a.res[b].flags |= 8 | (a.slot_flags[ls] << 8) | (total > KS ? (RT_F_FEAT_OVERFLOW << 8) : 0);
+            a.res[b].n_after_retrack = m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
+{
+    const int W = a.W, R = a.slots;
+    for (int first = 0; first < B; first += R) {
+        const int P = min(R, B - first);
+        hipError_t e = hipMemsetAsync(a.row_cnt, 0, sizeof(int32_t) * (size_t)P * (W + 1), st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
+        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((W + RT_TW - 1) / RT_TW, (W + RT_TH - 1) / RT_TH, P), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
+        e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, P, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, first);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rt_append_kernel, dim3(P), dim3(256), 0, st, a, first);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, const RtArgs &a)
+{
+    hipLaunchKernelGGL(rt_collect_kernel, dim3(1), dim3(256), 0, st, res, scan_idx, B, a.rt_lane, a.rt_scan, a.rt_n);
+    return hipGetLastError();
+}
+
+size_t retrack_slot_bytes(int W)
+{
+    return (size_t)W * W * (sizeof(double) + 1) + sizeof(int32_t) * (W + 1) + BP_MAX_PTS * (sizeof(uint32_t) + sizeof(double) + 3 * sizeof(double) + 5 * sizeof(int32_t))
+           + BP_MAX_TASKS * sizeof(BpTask) + (BP_MAX_PAIRS + 1) * (sizeof(uint32_t) + sizeof(uint16_t)) + 2 * 131072 * sizeof(uint16_t);
+}

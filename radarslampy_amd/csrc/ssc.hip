@@ -13,11 +13,10 @@
 
 #define SSC_BITMAP_BYTES 65536
 
-__global__ __launch_bounds__(64) void ssc_kernel(const double *__restrict__ kp, int B, int num_ret, double tol,
-                                                 int cols, int rows, int32_t *__restrict__ work,
-                                                 int32_t *__restrict__ sel, int32_t *__restrict__ n_sel)
+__device__ __forceinline__ void ssc_body(const double *__restrict__ kp, int B, int num_ret, double tol, int cols, int rows,
+                                         int32_t *__restrict__ work, int32_t *__restrict__ sel, int32_t *__restrict__ n_sel,
+                                         uint32_t *bitmap)
 {
-    extern __shared__ uint32_t bitmap[];
     const int lane = threadIdx.x;
     int32_t *resA = work, *resB = work + B, *accr = work + 2 * (size_t)B, *accq = work + 3 * (size_t)B;
     const double exp1 = (double)rows + cols + 2 * num_ret;
@@ -109,6 +108,39 @@ __global__ __launch_bounds__(64) void ssc_kernel(const double *__restrict__ kp, 
     __syncthreads();
     for (int i = lane; i < nfinal; i += 64) sel[i] = final_list[i];
     if (lane == 0) *n_sel = nfinal;
+}
+
+__global__ __launch_bounds__(64) void ssc_kernel(const double *__restrict__ kp, int B, int num_ret, double tol,
+                                                 int cols, int rows, int32_t *__restrict__ work,
+                                                 int32_t *__restrict__ sel, int32_t *__restrict__ n_sel)
+{
+    extern __shared__ uint32_t bitmap[];
+    ssc_body(kp, B, num_ret, tol, cols, rows, work, sel, n_sel, bitmap);
+}
+
+// batched: problem p = blockIdx.x (skipped when first + p >= *n_active): kp + p * kp_stride (rows of 3 doubles), count[p]
+// keypoints, work + p * 4 * kp_cap, sel + p * kp_cap
+__global__ __launch_bounds__(64) void ssc_batch_kernel(const double *__restrict__ kp, int64_t kp_stride, const int32_t *__restrict__ count,
+                                                       int kp_cap, int num_ret, double tol, int cols, int rows,
+                                                       int32_t *__restrict__ work, int32_t *__restrict__ sel,
+                                                       int32_t *__restrict__ n_sel, const int32_t *__restrict__ n_active, int first)
+{
+    extern __shared__ uint32_t bitmap[];
+    const int p = blockIdx.x;
+    if (first + p >= *n_active) return;
+    const int B = min(count[p], kp_cap);
+    if (B <= 0) { if (threadIdx.x == 0) n_sel[p] = 0; return; }
+    ssc_body(kp + (int64_t)p * kp_stride, B, num_ret, tol, cols, rows, work + (int64_t)p * 4 * kp_cap, sel + (int64_t)p * kp_cap,
+             n_sel + p, bitmap);
+}
+
+hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride, const int32_t *count, int kp_cap, int P,
+                            int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
+                            const int32_t *n_active, int first)
+{
+    hipLaunchKernelGGL(ssc_batch_kernel, dim3(P), dim3(64), SSC_BITMAP_BYTES, st, kp, kp_stride, count, kp_cap, num_ret, tol, cols,
+                       rows, work, sel, n_sel, n_active, first);
+    return hipGetLastError();
 }
 
 hipError_t launch_ssc(hipStream_t st, const double *kp, int B, int num_ret, double tol, int cols,

@@ -14,11 +14,12 @@ from . import _ffi
 class Engine:
     def __init__(self, lanes: int, pool_scans: int, ctx: _ffi.Context = None, rows=400, stride=3779, payload_off=11,
                  clip=2025, peaks_cap=65536, reject_outliers=True, motion_distortion=True, clique_node_limit=0,
-                 sigma5=(4.0, 4.0, 1.0, 1.0, (5 * np.pi / 180) ** 2)):
+                 sigma5=(4.0, 4.0, 1.0, 1.0, (5 * np.pi / 180) ** 2), retrack_on_device=False, retrack_slots=0):
         self.ctx = ctx or _ffi.default_context()
         self.lib = self.ctx.lib
         cfg = _ffi.EngineCfg(lanes, rows, stride, payload_off, clip, pool_scans, peaks_cap, int(reject_outliers),
-                             int(motion_distortion), int(clique_node_limit), (C.c_double * 5)(*sigma5))
+                             int(motion_distortion), int(clique_node_limit), (C.c_double * 5)(*sigma5), int(retrack_on_device),
+                             int(retrack_slots))
         self.cfg = cfg
         self.lanes, self.pool_scans = lanes, pool_scans
         self.rows, self.stride = rows, stride
@@ -53,6 +54,11 @@ class Engine:
         pose = np.ascontiguousarray(pose, np.float64)
         self.ctx.check(self.lib.roam_engine_init_lane(self.ctx.h, int(lane), int(pool_idx), _ffi._ptr(pts), pts.shape[0],
                                                       _ffi._ptr(pose)))
+
+    def init_lane_detect(self, lane: int, pool_idx: int, pose):
+        """init_lane with the first features detected on the device (needs retrack_on_device=True)"""
+        pose = np.ascontiguousarray(pose, np.float64)
+        self.ctx.check(self.lib.roam_engine_init_lane_detect(self.ctx.h, int(lane), int(pool_idx), _ffi._ptr(pose)))
 
     def set_features(self, lane: int, pts: np.ndarray):
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
@@ -95,15 +101,34 @@ class Engine:
     def synchronize(self):
         self.ctx.check(self.lib.roam_synchronize(self.ctx.h))
 
-    def results(self):
-        self.ctx.check(self.lib.roam_engine_results(self.ctx.h, self._res, self.lanes))
+    def steps_enqueued(self) -> int:
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.roam_engine_steps_enqueued(self.ctx.h, C.byref(n)))
+        return n.value
+
+    def results_array(self, step: int = None):
+        """the same records as one structured numpy array (pose, velocity, counts, flags): cheap for thousands of lanes"""
+        if step is None:
+            self.ctx.check(self.lib.roam_engine_results(self.ctx.h, self._res, self.lanes))
+        else:
+            self.ctx.check(self.lib.roam_engine_step_results(self.ctx.h, int(step), self._res, self.lanes))
+        return np.ctypeslib.as_array(self._res).copy()
+
+    def results(self, step: int = None):
+        """per-lane records of the last step, or of step `step` (0-based; only that step is waited for - the ring keeps
+        the last 8 steps, so poses / flags can be consumed while later steps are still running)"""
+        if step is None:
+            self.ctx.check(self.lib.roam_engine_results(self.ctx.h, self._res, self.lanes))
+        else:
+            self.ctx.check(self.lib.roam_engine_step_results(self.ctx.h, int(step), self._res, self.lanes))
         out = []
         for r in self._res:
             out.append(dict(pose=np.array(r.pose[:]), velocity=np.array(r.velocity[:]),
                             R=np.array(r.kabsch_R[:]).reshape(2, 2), h=np.array(r.kabsch_h[:]).reshape(2, 1),
                             n_tracked=r.n_tracked, n_good=r.n_good, n_inliers=r.n_inliers, n_peaks=r.n_peaks,
                             lm_nfev=r.lm_nfev, lm_info=r.lm_info, clique_proven=bool(r.flags & 1),
-                            new_keyframe=bool(r.flags & 2), retrack=bool(r.flags & 4)))
+                            new_keyframe=bool(r.flags & 2), retrack=bool(r.flags & 4), retracked_on_device=bool(r.flags & 8),
+                            detect_overflow=(r.flags >> 8) & 15, n_after_retrack=r.n_after_retrack))
         return out
 
     def lane_features(self, lane: int):

@@ -1,0 +1,155 @@
+"""GPU (-m gpu): feature (re)detection INSIDE roam_engine_step (retrack.hip) - appendNewFeatures of the reference's loop
+(RawROAMSystem.py:250-271, getFeatures.py:74-118) without a host round trip - against the oracle's loop body, on synthetic
+sequences and on the reference's 11 real data/tiny scans."""
+import numpy as np
+import pytest
+
+import oracle
+from test_oracle_reference_dump import FIX, W
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-4   # m
+ANG_TOL = 1e-5   # rad
+
+
+def _detect(cart):
+    return oracle.getFeatures(cart)[0]
+
+
+def _same_pose(got, want, tag):
+    assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= POS_TOL and abs(got["pose"][2] - want["pose"][2]) <= ANG_TOL, (tag, got["pose"], want["pose"])
+
+
+def test_init_lane_detect_matches_get_features():
+    """first-frame appendNewFeatures(prevImgCart, empty) on the device == oracle getFeatures (DoH, skimage-order pruning,
+    numpy-1.22 sigma order, SSC), as float32 [x, y] in ANMS order"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, _ = synth.make_sequence(21, 2, n_movers=8)
+    ctx = _ffi.Context(0)
+    eng = Engine(2, 2, ctx=ctx, retrack_on_device=True)
+    for t in range(2):
+        eng.upload_scan(t, recs[t])
+    for b in range(2):
+        eng.init_lane_detect(b, b, poses[0])
+        cart = oracle.convertPolarImageToCartesian(recs[b][:, 11:11 + 2025].astype(np.float32) / np.float32(255.))
+        want = oracle.append_dedupe(np.empty((0, 2)), _detect(cart))
+        got = eng.lane_features(b)
+        assert 180 <= len(want) <= 220
+        assert np.array_equal(got, want), (b, len(got), len(want))
+        kf = eng.map_keyframe(b, 0)
+        assert kf["scan"] == b and np.allclose(kf["pose"], poses[0])
+        okf = oracle.Keyframe(poses[0], (want - oracle.RADAR_CART_CENTER) * oracle.RANGE_RESOLUTION_CART_M, None, np.zeros(3), with_peaks=False)
+        assert np.abs(kf["prunedUndistortedLocals"] - okf.prunedUndistortedLocals).max() <= 1e-9
+    eng.close()
+    ctx.close()
+
+
+def test_engine_device_retrack_matches_oracle():
+    """lanes starting with few features run into the retrack branch at different steps; lanes with plenty never do.  No host
+    involvement between steps; features, keyframes and poses follow the oracle's loop body step by step."""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(1, 6, n_movers=6, distortion=True)
+    T = len(recs)
+    starts = [feat[:64], feat[:20], feat, feat[:0], feat[100:161]]
+    B = len(starts)
+    ctx = _ffi.Context(0)
+    eng = Engine(B, T, ctx=ctx, retrack_on_device=True, retrack_slots=2)      # 5 lanes through 2 scratch slots: chunking
+    eng.map_reserve(8)
+    for t in range(T):
+        eng.upload_scan(t, recs[t])
+    pipes = []
+    for b, f in enumerate(starts):
+        eng.init_lane(b, 0, f, poses[0])
+        pipes.append(oracle.OdometryPipeline(recs[0], f, poses[0], detect=_detect))
+    n_rt = 0
+    for t in range(1, T):
+        eng.step([t] * B)
+        res = eng.results()
+        for b in range(B):
+            want = pipes[b].step(recs[t])
+            got = res[b]
+            tag = (t, b)
+            assert got["n_tracked"] == want["n_tracked"] and got["n_inliers"] == want["n_inliers"], tag
+            assert got["retrack"] == bool(want["retrack"]) and got["retracked_on_device"] == bool(want["retrack"]), tag
+            assert got["detect_overflow"] == 0, tag
+            assert np.array_equal(eng.lane_features(b), pipes[b].blobCoord), tag
+            if got["retrack"]:
+                n_rt += 1
+                assert got["n_after_retrack"] == len(pipes[b].blobCoord), tag
+            _same_pose(got, want, tag)
+            kf = eng.live_keyframe(b)
+            assert kf["prunedUndistortedLocals"].shape == pipes[b].old_kf.prunedUndistortedLocals.shape, tag
+            assert np.abs(kf["prunedUndistortedLocals"] - pipes[b].old_kf.prunedUndistortedLocals).max() <= 1e-4, tag
+    assert n_rt >= 4
+    eng.close()
+    ctx.close()
+
+
+def test_device_retrack_on_the_reference_real_scans():
+    """the reference's 11 real data/tiny scans through a 1-lane engine with device-side detection and retracks (features
+    collapse from ~200 to < 60 within two or three real frames) vs the oracle's loop body, every step"""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    fix = np.load(FIX)
+    pay = fix["payload"]
+    T, rows, clip = pay.shape
+    ctx = _ffi.Context(0)
+    eng = Engine(1, T, ctx=ctx, rows=rows, stride=clip, payload_off=0, clip=clip, retrack_on_device=True)
+    for t in range(T):
+        eng.upload_scan(t, np.ascontiguousarray(pay[t]))
+    pose0 = np.zeros(3)
+    eng.init_lane_detect(0, 0, pose0)
+    cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), _detect(cart0))
+    assert np.array_equal(eng.lane_features(0), feat0)
+    pipe = oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), feat0, pose0, detect=_detect, payload_off=0, clip=clip)
+    n_rt = 0
+    for t in range(1, T):
+        eng.step([t])
+        got = eng.results()[0]
+        want = pipe.step(np.ascontiguousarray(pay[t]))
+        assert got["n_tracked"] == want["n_tracked"] and got["n_good"] == want["n_good"] and got["n_inliers"] == want["n_inliers"], t
+        assert got["retrack"] == bool(want["retrack"]), t
+        assert np.array_equal(eng.lane_features(0), pipe.blobCoord), t
+        _same_pose(got, want, t)
+        n_rt += got["retrack"]
+    assert n_rt >= 2, n_rt
+    # the vehicle of data/tiny drives ~2 m per frame: ten frames of dead-reckoned motion-distortion poses
+    assert 10.0 < np.hypot(*got["pose"][:2]) < 40.0, got["pose"]
+    eng.close()
+    ctx.close()
+
+
+def test_step_results_ring_does_not_drain_the_pipeline():
+    """every step's records stay retrievable (ring of 8) while later steps are enqueued: results(step) == the records a
+    synchronised run produced for that step"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(3, 7, n_movers=4, distortion=True)
+    T = len(recs)
+    ctx = _ffi.Context(0)
+
+    def run(sync):
+        eng = Engine(2, T, ctx=ctx, retrack_on_device=True)
+        for t in range(T):
+            eng.upload_scan(t, recs[t])
+        for b in range(2):
+            eng.init_lane(b, 0, feat[:70 + 300 * b], poses[0])
+        out = []
+        for t in range(1, T):
+            eng.step([t, t])
+            if sync:
+                out.append(eng.results_array())
+        if not sync:
+            assert eng.steps_enqueued() == T - 1
+            out = [eng.results_array(step=k) for k in range(T - 1)]
+        eng.close()
+        return out
+
+    a, b = run(True), run(False)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x.tobytes() == y.tobytes(), k
+    ctx.close()
