@@ -102,6 +102,12 @@ int32_t roam_reject_outliers(roam_ctx *ctx, const float *prev, const float *next
                              double thr_px, int64_t node_limit, uint8_t *mask_out,
                              int32_t *n_inliers, int32_t *flags_out, uint64_t *adj_out);
 
+/* measurement aid: the same correspondence set replicated `copies` times (one problem each, as in an engine step);
+ * average ms per launch of the consistency-graph and the maximum-clique kernel over `reps` launches */
+int32_t roam_time_reject_outliers(roam_ctx *ctx, const float *prev, const float *next, int32_t K, int32_t copies,
+                                  double thr_px, int64_t node_limit, int32_t reps, float *graph_ms, float *clique_ms,
+                                  int32_t *n_inliers, int32_t *proven);
+
 /* ---- a10: getTransformKLT.calculateTransformSVD (getTransformKLT.py:129-162) -------------
  * src ~= R tgt + h over N pairs of float64 [x,y]; R row-major [4], h [2]. */
 int32_t roam_kabsch2d(roam_ctx *ctx, const double *src, const double *tgt, int32_t N,

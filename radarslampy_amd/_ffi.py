@@ -59,6 +59,8 @@ _SIGS = {
     "roam_klt_track_f32": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, _vp]),
     "roam_pyr_down_u8": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     "roam_reject_outliers": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_double, C.c_int64, _vp, _P(C.c_int32), _P(C.c_int32), _vp]),
+    "roam_time_reject_outliers": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_int64, C.c_int32, _P(C.c_float), _P(C.c_float),
+                                               _P(C.c_int32), _P(C.c_int32)]),
     "roam_kabsch2d": (C.c_int32, [_vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "roam_mds_solve": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_double, _vp, _P(C.c_int32), _P(C.c_int32), _vp, _vp]),
     "roam_mds_undistort": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_double, _vp, _vp]),
@@ -242,6 +244,15 @@ class Context:
         self.check(self.lib.roam_reject_outliers(self.h, _ptr(prev), _ptr(new), K, float(thr_px), int(node_limit),
                                                  _ptr(mask), C.byref(n_in), C.byref(flags), _ptr(adj)))
         return mask.astype(bool), n_in.value, flags.value, adj
+
+    def time_reject_outliers(self, prev, new, thr_px, copies=4096, reps=3, node_limit=0):
+        """(graph ms, clique ms, inliers, proven) per launch of `copies` replicas of one correspondence set"""
+        p = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+        n = np.ascontiguousarray(new, np.float32).reshape(-1, 2)
+        g, q, ni, pr = C.c_float(0), C.c_float(0), C.c_int32(0), C.c_int32(0)
+        self.check(self.lib.roam_time_reject_outliers(self.h, _ptr(p), _ptr(n), p.shape[0], int(copies), float(thr_px), int(node_limit), int(reps),
+                                                      C.byref(g), C.byref(q), C.byref(ni), C.byref(pr)))
+        return float(g.value), float(q.value), ni.value, bool(pr.value)
 
     def kabsch2d(self, src, tgt):
         s = np.ascontiguousarray(src, np.float64).reshape(-1, 2)

@@ -307,6 +307,50 @@ extern "C" int32_t roam_reject_outliers(roam_ctx *ctx, const float *prev, const 
     return ROAM_OK;
 }
 
+// throughput of a8 on one correspondence set replicated `copies` times (each copy its own problem, as in an engine step):
+// average milliseconds per launch of the consistency-graph and the maximum-clique kernel over `reps` launches
+extern "C" int32_t roam_time_reject_outliers(roam_ctx *ctx, const float *prev, const float *next, int32_t K, int32_t copies,
+                                             double thr_px, int64_t node_limit, int32_t reps, float *graph_ms, float *clique_ms,
+                                             int32_t *n_inliers, int32_t *proven)
+{
+    ENTER();
+    ARG_CHECK(ctx, K >= 1 && K <= ROAM_MAX_FEATURES && prev && next && copies >= 1 && copies <= 65536 && reps >= 1 && graph_ms && clique_ms);
+    const int nw = (K + 63) / 64;
+    SCRATCH(dp, float, S_IN0, sizeof(float) * 2 * (size_t)K * copies);
+    SCRATCH(dn, float, S_IN1, sizeof(float) * 2 * (size_t)K * copies);
+    SCRATCH(dadj, uint64_t, S_TMP0, sizeof(uint64_t) * (size_t)K * nw * copies);
+    SCRATCH(dstk, uint64_t, S_TMP1, sizeof(uint64_t) * (size_t)(K + 2) * 2 * nw * copies);
+    SCRATCH(dmask, uint8_t, S_OUT0, (size_t)K * copies);
+    SCRATCH(dres, int32_t, S_OUT1, sizeof(int32_t) * 2 * (size_t)copies);
+    for (int c = 0; c < copies; c++) {
+        H2D(dp + 2 * (size_t)K * c, prev, sizeof(float) * 2 * (size_t)K);
+        H2D(dn + 2 * (size_t)K * c, next, sizeof(float) * 2 * (size_t)K);
+    }
+    hipEvent_t e0, e1, e2;
+    HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1)); HIP_TRY(ctx, hipEventCreate(&e2));
+    double g = 0, q = 0;
+    for (int r = 0; r < reps; r++) {
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        HIP_TRY(ctx, launch_consistency_graph(ctx->stream, dp, dn, nullptr, K, K, copies, thr_px, dadj, nw));
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, launch_max_clique(ctx->stream, dadj, nullptr, K, K, nw, copies, node_limit, dstk, dmask, dres, dres + copies));
+        HIP_TRY(ctx, hipEventRecord(e2, ctx->stream));
+        SYNC();
+        float a = 0, b = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, e0, e1)); HIP_TRY(ctx, hipEventElapsedTime(&b, e1, e2));
+        g += a; q += b;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    *graph_ms = (float)(g / reps); *clique_ms = (float)(q / reps);
+    int32_t res[2];
+    D2H(&res[0], dres + (copies - 1), sizeof(int32_t));
+    D2H(&res[1], dres + copies + (copies - 1), sizeof(int32_t));
+    SYNC();
+    if (n_inliers) *n_inliers = res[0];
+    if (proven) *proven = res[1];
+    return ROAM_OK;
+}
+
 extern "C" int32_t roam_kabsch2d(roam_ctx *ctx, const double *src, const double *tgt, int32_t N,
                                  double *R, double *h)
 {

@@ -13,12 +13,12 @@
 // max_clique_kernel: ONE WAVEFRONT PER PROBLEM.  Bitsets (<= 16 words for K <= 1024) are
 //   held one word per lane; set algebra is one VALU op, population counts and first-set
 //   searches are ballot / shuffle reductions.  Adjacency rows live in LDS when they fit
-//   (K*nw*8 <= 64 KB) and are read through L2 otherwise.  Search = greedy minimum-degree
-//   peeling for a lower bound, k-core reduction, then an exact depth-first branch and
-//   bound in ascending vertex order with a greedy-colouring upper bound; visiting cliques
-//   in lexicographic order and accepting only strict improvements yields the
-//   lexicographically smallest maximum clique.  The DFS stack sits in a global scratch
-//   slab (nw words per level, L2-resident).  No MFMA: the work is integer bit algebra.
+//   (K*nw*8 <= 64 KB) and are read through L2 otherwise.  Search (see cq_solve): the graph is
+//   dense, its complement sparse, so omega comes from a reduction-driven branch and bound on the
+//   conflict graph (k-core, universal and pendant vertices, matching bound, branching on the most
+//   conflicting vertex); the lexicographically smallest maximum clique then follows by fixing
+//   vertices in ascending order with bounded existence queries.  The DFS stack sits in a global
+//   scratch slab (nw words per level, L2-resident).  No MFMA: the work is integer bit algebra.
 #include "roam_internal.h"
 
 #define CG_ROWS 8       // adjacency rows per workgroup
@@ -92,67 +92,128 @@ __device__ __forceinline__ int bs_first(uint64_t x)
 }
 __device__ __forceinline__ uint64_t bit_if(int lane, int v) { return (lane == (v >> 6)) ? (1ull << (v & 63)) : 0ull; }
 
-// number of colour classes of a greedy sequential colouring of P, stopping early once it
-// exceeds `need` (the caller only asks whether colours(P) > need)
-__device__ int colour_bound(uint64_t P, const uint64_t *A, int as, int nw, int lane, int need)
-{
-    uint64_t U = P;
-    int c = 0;
-    while (__ballot(U != 0)) {
-        c++;
-        if (c > need) return c;
-        uint64_t Q = U;
-        for (;;) {
-            int v = bs_first(Q);
-            if (v < 0) break;
-            uint64_t row = (lane < nw) ? A[(int64_t)v * as + lane] : 0ull;
-            uint64_t bv = bit_if(lane, v);
-            Q &= ~(row | bv);
-            U &= ~bv;
-        }
-    }
-    return c;
-}
-
 #define CQ_LDS_ADJ_WORDS 8192          // 64 KB of adjacency rows in LDS (compact stride)
 
-// Node reduction (wave-parallel over vertices, 64 at a time):
-//   * k-core: a vertex with fewer than (best - size) neighbours inside NP cannot belong to a
-//     clique that beats `best` -> removed, iterated to a fixed point;
-//   * universal vertices (adjacent to every other vertex of NP) belong to EVERY maximum clique
-//     of this subproblem -> moved into R at once.  Adding elements common to all candidates
-//     does not change their lexicographic order, so the canonical result is preserved.
-// Returns |NP| after reduction, or -1 when the subproblem cannot beat `best`.
-__device__ int reduce_node(uint64_t &NP, uint64_t &R, int &size, int best, const uint64_t *A, int as,
-                           int nw, int lane, uint64_t *sw)
+// ---------------------------------------------------------------------------------------------- exact search
+// The consistency graph of a scan pair is DENSE: the static features form one large clique and every other vertex is
+// adjacent to most of it (median degree 217 of 239 on a 240-feature pair right after a re-detection; maximum clique 155).
+// Its complement H - the "conflict" graph - is sparse, so the search is organised as a maximum-independent-set solver on
+// H: per node a wave-parallel degree pass (64 vertices at a time, one popcount per adjacency word) drives
+//   * k-core:     fewer than (best - size) neighbours inside P            -> cannot be in an improving clique, removed
+//   * universal:  no conflict left inside P (H-degree 0)                  -> in every maximum clique of P, taken
+//   * pendant:    exactly one conflict u (H-degree 1)                     -> SOME maximum clique of P contains it: taken, u removed
+// to a fixed point; what remains is bounded by |P| - |greedy maximal matching of H[P]| (each conflict edge of a matching
+// costs one vertex) and branched on the vertex with the most conflicts: first WITHOUT it (this descent is the classical
+// minimum-degree peeling and finds a near-optimal clique at once), then with it.
+// cq_solve answers "size of a maximum clique inside P0, if it exceeds `best`" and stops early at `target`.
+struct CqCtx {
+    const uint64_t *A;          // adjacency rows (LDS or global), stride `as` words
+    int as, nw, nws, lane;
+    uint64_t *sw;               // 16 words of LDS: the current set broadcast to all lanes
+    uint64_t *stk;              // global scratch: 2 * nws words per level
+    short *lsize, *lv, *lstage; // per level: |R|, branching vertex, stage
+    long long nodes, node_limit;
+    bool complete;
+};
+
+__device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &REC)
 {
+    const int lane = c.lane, nw = c.nw;
+    uint64_t P = P0, R = 0;
+    int size = 0, depth = -1;
+    bool pending = true;
     for (;;) {
-        const int cnt = bs_count(NP);
-        if (size + cnt <= best) return -1;
-        if (cnt == 0) return 0;
-        if (lane < 16) sw[lane] = NP;
-        __syncthreads();
-        const int thr = best - size;
-        uint64_t RM = 0, UN = 0;
-        for (int g = 0; g < nw; g++) {
-            const int u = g * 64 + lane;
-            const bool in = (sw[g] >> lane) & 1ull;
-            int d = 0;
-            if (in)
-                for (int w = 0; w < nw; w++) d += __popcll(A[(int64_t)u * as + w] & sw[w]);
-            const uint64_t brm = __ballot(in && d < thr);
-            const uint64_t bun = __ballot(in && d == cnt - 1);
-            if (lane == g) { RM = brm; UN = bun; }
+        if (pending) {
+            pending = false;
+            int vbr = -1;
+            bool dead = false;
+            for (;;) {                                                  // reductions to a fixed point
+                const int cnt = bs_count(P);
+                if (size + cnt <= best) { dead = true; break; }
+                if (cnt == 0) break;
+                if (lane < 16) c.sw[lane] = P;
+                __syncthreads();
+                const int thr = best - size;                            // an improving clique needs >= thr neighbours inside P
+                uint64_t RM = 0, UN = 0, PE = 0;
+                int key = 0x7fffffff;
+                for (int g = 0; g < nw; g++) {
+                    const int u = g * 64 + lane;
+                    const bool in = (c.sw[g] >> lane) & 1ull;
+                    int d = 0;
+                    if (in)
+                        for (int w = 0; w < nw; w++) d += __popcll(c.A[(int64_t)u * c.as + w] & c.sw[w]);
+                    const uint64_t brm = __ballot(in && d < thr);
+                    const uint64_t bun = __ballot(in && d == cnt - 1);
+                    const uint64_t bpe = __ballot(in && d == cnt - 2);
+                    if (lane == g) { RM = brm; UN = bun; PE = bpe; }
+                    if (in) key = min(key, d * 2048 + (2047 - u));      // fewest neighbours = most conflicts; ties: largest index
+                }
+                __syncthreads();
+                if (__ballot(RM != 0)) { P &= ~RM; continue; }
+                if (__ballot(UN != 0)) { R |= UN; size += bs_count(UN); P &= ~UN; continue; }
+                const int pv = bs_first(PE);
+                if (pv >= 0) {
+                    const uint64_t row = (lane < nw) ? c.A[(int64_t)pv * c.as + lane] : 0ull;
+                    const uint64_t bv = bit_if(lane, pv);
+                    const int pu = bs_first(P & ~row & ~bv);           // its only conflict
+                    R |= bv; size++;
+                    P &= ~(bv | bit_if(lane, pu));
+                    continue;
+                }
+                key = wave_min_i(key);
+                vbr = 2047 - (key & 2047);
+                break;
+            }
+            if (dead) continue;
+            if (bs_count(P) == 0) {                                     // a maximal clique of this branch
+                if (size > best) { best = size; REC = R; if (best >= target) return best; }
+                continue;
+            }
+            c.nodes++;
+            if (c.node_limit > 0 && c.nodes > c.node_limit) { c.complete = false; return best; }
+            // matching bound on the conflict graph of P
+            {
+                const int cnt = bs_count(P);
+                uint64_t Q = P;
+                int slack = size + cnt - best;                          // prune once the matching reaches `slack`
+                bool pruned = false;
+                for (;;) {
+                    const int v = bs_first(Q);
+                    if (v < 0) break;
+                    const uint64_t row = (lane < nw) ? c.A[(int64_t)v * c.as + lane] : 0ull;
+                    const uint64_t bv = bit_if(lane, v);
+                    const int u = bs_first(Q & ~row & ~bv);
+                    Q &= ~bv;
+                    if (u < 0) continue;
+                    Q &= ~bit_if(lane, u);
+                    if (--slack <= 0) { pruned = true; break; }
+                }
+                if (pruned) continue;
+            }
+            depth++;
+            if (lane < nw) {
+                c.stk[((int64_t)depth * 2) * c.nws + lane] = P;
+                c.stk[((int64_t)depth * 2 + 1) * c.nws + lane] = R;
+            }
+            if (lane == 0) { c.lsize[depth] = (short)size; c.lv[depth] = (short)vbr; c.lstage[depth] = 0; }
+            __syncthreads();
+            continue;
         }
+        if (depth < 0) return best;
+        const int stage = c.lstage[depth], v = c.lv[depth], sl = c.lsize[depth];
         __syncthreads();
-        if (__ballot(RM != 0)) { NP &= ~RM; continue; }
-        if (__ballot(UN != 0)) {
-            R |= UN;
-            size += bs_count(UN);
-            NP &= ~UN;
-            return bs_count(NP);
+        if (stage >= 2) { depth--; continue; }
+        if (lane == 0) c.lstage[depth] = (short)(stage + 1);
+        const uint64_t Pl = (lane < nw) ? c.stk[((int64_t)depth * 2) * c.nws + lane] : 0ull;
+        const uint64_t Rl = (lane < nw) ? c.stk[((int64_t)depth * 2 + 1) * c.nws + lane] : 0ull;
+        if (sl + bs_count(Pl) <= best) { depth--; continue; }
+        const uint64_t bv = bit_if(lane, v);
+        if (stage == 0) { P = Pl & ~bv; R = Rl; size = sl; }           // without the most conflicting vertex
+        else {
+            const uint64_t row = (lane < nw) ? c.A[(int64_t)v * c.as + lane] : 0ull;
+            P = Pl & row; R = Rl | bv; size = sl + 1;                   // with it: its conflicts leave
         }
-        return cnt;
+        pending = true;
     }
 }
 
@@ -172,105 +233,62 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
         return;
     }
     const int nw = (Kb + 63) >> 6;                 // active words per bitset
-    // ---- LDS carve: deg[K] int, lsize[K+2] short, sw[16] u64, adjacency (compact stride nw)
-    int *deg = reinterpret_cast<int *>(cq_smem);
-    short *lsize = reinterpret_cast<short *>(deg + K);
-    uint64_t *sw = reinterpret_cast<uint64_t *>(cq_smem + ((sizeof(int) * K + sizeof(short) * (K + 2) + 15) & ~(size_t)15));
+    // ---- LDS carve: three short[K+2] level arrays, sw[16] u64, adjacency (compact stride)
+    short *lsize = reinterpret_cast<short *>(cq_smem);
+    short *lv = lsize + (K + 2), *lstage = lv + (K + 2);
+    uint64_t *sw = reinterpret_cast<uint64_t *>(cq_smem + ((3 * sizeof(short) * (K + 2) + 15) & ~(size_t)15));
     uint64_t *adj_l = sw + 16;
     const uint64_t *Ag = adj_g + (int64_t)b * kstride * nws;
     const bool use_lds = (Kb * nw <= CQ_LDS_ADJ_WORDS);
-    const uint64_t *A;
-    int as;
+    CqCtx c;
     if (use_lds) {
         for (int i = lane; i < Kb * nw; i += 64) {
             const int r = i / nw, w = i - r * nw;
             adj_l[i] = Ag[(int64_t)r * nws + w];
         }
-        A = adj_l; as = nw;
-    } else { A = Ag; as = nws; }
+        c.A = adj_l; c.as = nw;
+    } else { c.A = Ag; c.as = nws; }
     __syncthreads();
-    uint64_t *stk = stack_g + (int64_t)b * (kstride + 2) * 2 * nws;
+    c.nw = nw; c.nws = nws; c.lane = lane; c.sw = sw;
+    c.stk = stack_g + (int64_t)b * (kstride + 2) * 2 * nws;
+    c.lsize = lsize; c.lv = lv; c.lstage = lstage;
+    c.nodes = 0; c.node_limit = node_limit; c.complete = true;
 
-    // all-vertices set in word-per-lane layout
-    uint64_t ALL = 0;
+    uint64_t ALL = 0;                               // all-vertices set in word-per-lane layout
     if (lane < nw) {
-        int lo = lane * 64;
+        const int lo = lane * 64;
         if (Kb >= lo + 64) ALL = ~0ull;
         else if (Kb > lo) ALL = (1ull << (Kb - lo)) - 1ull;
     }
-
-    // ---- greedy lower bound: peel the minimum-degree vertex (ties: largest index) until clique
-    uint64_t S = ALL;
-    int sizeS = Kb;
-    if (lane < 16) sw[lane] = S;
-    __syncthreads();
-    for (int u = lane; u < Kb; u += 64) {
-        int dsum = 0;
-        for (int w = 0; w < nw; w++) dsum += __popcll(A[(int64_t)u * as + w] & sw[w]);
-        deg[u] = dsum;
-    }
-    __syncthreads();
-    for (;;) {
-        if (lane < 16) sw[lane] = S;
-        __syncthreads();
-        int key = 0x7fffffff;
-        for (int u = lane; u < Kb; u += 64)
-            if ((sw[u >> 6] >> (u & 63)) & 1ull) key = min(key, deg[u] * 2048 + (2047 - u));
-        key = wave_min_i(key);
-        const int dmin = key >> 11, u0 = 2047 - (key & 2047);
-        if (dmin >= sizeS - 1) break;
-        S &= ~bit_if(lane, u0);
-        sizeS--;
-        __syncthreads();
-        for (int x = lane; x < Kb; x += 64)
-            if ((A[(int64_t)x * as + (u0 >> 6)] >> (u0 & 63)) & 1ull) deg[x]--;
-        __syncthreads();
-    }
-    const int LB = sizeS;
-    uint64_t REC = S;               // best clique recorded so far (the greedy one to start with)
-    int best = LB - 1;              // threshold: find the lexicographically first clique of size >= LB
-
-    // ---- exact search in ascending vertex order (levels hold {untried candidates, R, |R|})
-    long long nodes = 0;
-    int depth = -1;
-    bool complete = true;
-    uint64_t NP = ALL, Rn = 0;
-    int sz = 0;
-    bool pending = true;            // (NP, Rn, sz) is a subproblem waiting to be examined
-    for (;;) {
-        if (pending) {
-            pending = false;
-            const int c = reduce_node(NP, Rn, sz, best, A, as, nw, lane, sw);
-            if (c == 0) { if (sz > best) { best = sz; REC = Rn; } }
-            else if (c > 0) {
-                nodes++;
-                if (node_limit > 0 && nodes > node_limit) { complete = false; break; }
-                const int need = best - sz;                      // need colours(NP) > need
-                if (colour_bound(NP, A, as, nw, lane, need) > need) {
-                    depth++;
-                    if (lane < nw) {
-                        stk[((int64_t)depth * 2) * nws + lane] = NP;
-                        stk[((int64_t)depth * 2 + 1) * nws + lane] = Rn;
-                    }
-                    if (lane == 0) lsize[depth] = (short)sz;
-                }
+    // ---- phase 1: omega and one maximum clique (the witness)
+    uint64_t WIT = 0;
+    const int omega = cq_solve(c, ALL, 0, 0x7fffffff, WIT);
+    // ---- phase 2: the lexicographically smallest maximum clique.  Vertices are fixed in ascending order; v is taken iff
+    // a clique of the size still needed exists among the common neighbours above it.  The witness (a maximum clique that
+    // extends the choices made so far) answers "yes" for its own members without a search; every other vertex costs one
+    // bounded existence query, and a successful query replaces the witness.
+    uint64_t C = ALL, RF = 0;
+    int need = omega;
+    while (need > 0 && c.complete) {
+        const int v = bs_first(C);
+        if (v < 0) break;                                               // cannot happen for an exact omega
+        const uint64_t bv = bit_if(lane, v);
+        const uint64_t row = (lane < nw) ? c.A[(int64_t)v * c.as + lane] : 0ull;
+        const uint64_t S = C & row;                                    // C holds only vertices above the last decision
+        const bool inwit = __ballot((WIT & bv) != 0) != 0;
+        bool take = inwit;
+        if (!take && bs_count(S) >= need - 1) {
+            if (need == 1) { take = true; WIT = RF | bv; }
+            else {
+                uint64_t RQ = 0;
+                const int got = cq_solve(c, S, need - 2, need - 1, RQ);
+                if (got >= need - 1) { take = true; WIT = RF | bv | RQ; }
             }
-            continue;
         }
-        if (depth < 0) break;
-        uint64_t cand = (lane < nw) ? stk[((int64_t)depth * 2) * nws + lane] : 0ull;
-        const int sl = (int)lsize[depth];
-        const int v = bs_first(cand);
-        if (v < 0 || sl + bs_count(cand) <= best) { depth--; continue; }
-        cand &= ~bit_if(lane, v);
-        if (lane < nw) stk[((int64_t)depth * 2) * nws + lane] = cand;
-        const uint64_t Rl = (lane < nw) ? stk[((int64_t)depth * 2 + 1) * nws + lane] : 0ull;
-        const uint64_t row = (lane < nw) ? A[(int64_t)v * as + lane] : 0ull;
-        NP = cand & row;
-        Rn = Rl | bit_if(lane, v);
-        sz = sl + 1;
-        pending = true;
+        if (take) { RF |= bv; C = S; need--; }
+        else C &= ~bv;
     }
+    const uint64_t REC = (c.complete && need == 0) ? RF : WIT;          // incomplete search: the best clique known
 
     // ---- emit
     if (lane < 16) sw[lane] = REC;
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
     for (int u = lane; u < Kb; u += 64) mask[u] = (uint8_t)((sw[u >> 6] >> (u & 63)) & 1ull);
     for (int u = Kb + lane; u < kstride && u < K; u += 64) mask[u] = 0;
     const int cnt = bs_count(REC);
-    if (lane == 0) { n_in[b] = cnt; flags[b] = complete ? 1 : 0; }
+    if (lane == 0) { n_in[b] = cnt; flags[b] = c.complete ? 1 : 0; }
 }
 
 // adj rows have stride nws words; stack scratch: B x (kstride+2) x 2 x nws words
@@ -287,7 +305,7 @@ hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t 
                              uint8_t *mask, int32_t *n_in, int32_t *flags)
 {
     if (B <= 0 || K <= 0) return hipSuccess;
-    size_t lds = ((sizeof(int) * (size_t)K + sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 16 * 8;
+    size_t lds = ((3 * sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 16 * 8;
     const size_t kw = (size_t)K * ((K + 63) / 64);
     lds += 8 * (kw < CQ_LDS_ADJ_WORDS ? kw : (size_t)CQ_LDS_ADJ_WORDS);
     if (node_limit <= 0) node_limit = 300000;

@@ -78,8 +78,7 @@ struct Engine {
     roam_lane_result *results = nullptr;           // ring of RES_RING per-step records (RES_RING x B)
     roam_lane_result *results_host = nullptr;      // pinned mirror, filled asynchronously after every step
     hipEvent_t ev_res[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_resrdy = nullptr, ev_pool = nullptr;
-    hipStream_t s_res = nullptr;                    // asynchronous D2H of the per-step result records
+    hipEvent_t ev_pool = nullptr;
     bool pool_dirty = false;
     RtArgs rt;                                      // device-side retrack (retrack.hip)
     bool rt_on = false;
@@ -426,9 +425,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->results_host) hipHostFree(e->results_host);
     for (auto &ev : e->ev_res) if (ev) hipEventDestroy(ev);
-    if (e->ev_resrdy) hipEventDestroy(e->ev_resrdy);
     if (e->ev_pool) hipEventDestroy(e->ev_pool);
-    if (e->s_res) { hipStreamSynchronize(e->s_res); hipStreamDestroy(e->s_res); }
     if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
@@ -541,8 +538,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     }
     for (auto &ev : e->ev_res)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
-    if (hipEventCreateWithFlags(&e->ev_resrdy, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e->ev_pool, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->s_res, hipStreamNonBlocking) != hipSuccess) {
+    if (hipEventCreateWithFlags(&e->ev_pool, hipEventDisableTiming) != hipSuccess) {
         ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
     for (auto &ev : e->ev) {
@@ -909,11 +905,11 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     }
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
     HIP_TRY(ctx, hipEventRecord(e->ev_g4[k4], st));
-    // per-step result record -> pinned host ring, off the compute stream: roam_engine_step_results(step) waits for THIS copy only
-    HIP_TRY(ctx, hipEventRecord(e->ev_resrdy, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(e->s_res, e->ev_resrdy, 0));
-    HIP_TRY(ctx, hipMemcpyAsync(e->results_host + (size_t)rs * B, res_slot, sizeof(roam_lane_result) * (size_t)B, hipMemcpyDeviceToHost, e->s_res));
-    HIP_TRY(ctx, hipEventRecord(e->ev_res[rs], e->s_res));
+    // per-step result record -> pinned host ring: roam_engine_step_results(step) waits for THIS copy only
+    // (on the compute stream itself: a side stream waiting on an event here cost 11 % of the step rate - the extra stream
+    // shares a hardware queue with one of the pipeline's streams and serialises it; the 0.5 MB copy takes ~20 us)
+    HIP_TRY(ctx, hipMemcpyAsync(e->results_host + (size_t)rs * B, res_slot, sizeof(roam_lane_result) * (size_t)B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(e->ev_res[rs], st));
     e->cur = (e->cur + 1) & 3;
     e->pk = pb;
     e->nstep++;
