@@ -42,6 +42,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle, 1 core (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the N-core CPU leg (-1 = half the logical cores, 0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
+    ap.add_argument("--no-retrack", action="store_true", help="round-1 workload: host-seeded features, no re-detection in the timed loop")
+    ap.add_argument("--retrack-slots", type=int, default=0, help="lanes whose detection scratch is resident at once (0 = min(lanes, 512))")
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--h2d", action="store_true", help="stream every scan from pinned host memory over PCIe (double-buffered pool); reports the PCIe-inclusive rate")
     ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
@@ -103,12 +105,16 @@ class DryEngine:
 
 def cpu_worker(job):
     """one independent oracle pipeline (N-core leg of the CPU baseline); returns (pairs, seconds)"""
-    seed, frames, pairs, md = job
+    seed, frames, pairs, md, retrack = job
     import oracle
     from radarslampy_amd import synth
-    recs, poses, feat = synth.make_sequence(seed, frames, n_static=460, n_movers=24, distortion=md)
+    work = dict(n_static=460, n_movers=120, scintillation=0.6) if retrack else dict(n_static=460, n_movers=24)
+    recs, poses, feat = synth.make_sequence(seed, frames, distortion=md, **work)
     cyc = list(range(1, frames)) + list(range(frames - 2, -1, -1))
-    P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=md)
+    det = (lambda cart: oracle.getFeatures(cart)[0]) if retrack else None
+    if retrack:
+        feat = oracle.append_dedupe(np.empty((0, 2)), det(oracle.convertPolarImageToCartesian(recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.))))
+    P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=md, detect=det)
     t0 = time.perf_counter()
     for n in range(pairs):
         P.step(recs[cyc[n % len(cyc)]])
@@ -139,13 +145,20 @@ def run_rank(args):
         E = max(1, args.engines)
         assert B % E == 0
         BE = B // E
-        seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, n_static=460, n_movers=24, distortion=not args.no_md) for d in range(Dn_)]
+        # workload: reflector world with 120 movers and scan-to-scan scintillation: ~26 % of the tracked correspondences are
+        # rejected per pair (the paper reports 28 %) and features run out every ~3 pairs (real `tiny` scans: every 2-3), so
+        # the feature re-detection (DoH + ANMS) is part of the timed loop at the cadence the data dictates
+        WORK = dict(n_static=460, n_movers=24) if args.no_retrack else dict(n_static=460, n_movers=120, scintillation=0.6)
+        seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, distortion=not args.no_md, **WORK) for d in range(Dn_)]
         # every lane owns private copies of its T records (device-to-device replicas of the D distinct
         # sequences): identical content, distinct HBM addresses -> input reads are real HBM traffic
         ctxs = [ctx] + [_ffi.Context(local_rank) for _ in range(E - 1)]
         engs = []
+        period = 2 * T - 2
+        cyc_full = list(range(T)) + list(range(T - 2, 0, -1))          # ping-pong 0,1,..,T-1,T-2,..,1
         for e in range(E):
-            en = Engine(BE, BE * T, ctx=ctxs[e], motion_distortion=not args.no_md)
+            en = Engine(BE, BE * T, ctx=ctxs[e], motion_distortion=not args.no_md, retrack_on_device=not args.no_retrack,
+                        retrack_slots=args.retrack_slots)
             Dn = min(Dn_, BE)
             for d in range(Dn):
                 for t in range(T):
@@ -154,17 +167,21 @@ def run_rank(args):
                 for t in range(T):
                     en.copy_scan(b * T + t, (b % Dn) * T + t)
             en.synchronize()
+            # replicas of one sequence start at different frames of the cycle, so that their retracks do not coincide
+            en.phase = np.array([0 if (args.no_retrack or args.h2d) else (b // Dn) % period for b in range(BE)])
             for b in range(BE):
-                d = b % Dn
-                en.init_lane(b, b * T, seqs[d][2], seqs[d][1][0])
+                d, t0 = b % Dn, cyc_full[en.phase[b]]
+                if args.no_retrack:
+                    en.init_lane(b, b * T, seqs[d][2], seqs[d][1][0])
+                else:
+                    en.init_lane_detect(b, b * T + t0, seqs[d][1][t0])     # first features detected on the device (DoH + ANMS)
             engs.append(en)
         eng = engs[0]
+        cyc_arr = np.array(cyc_full)
 
         def step_all(i):
-            t = cyc[i % len(cyc)]
-            ix = np.arange(BE, dtype=np.int32) * T + t
             for en in engs:
-                en.step(ix)
+                en.step((np.arange(BE) * T + cyc_arr[(en.phase + i + 1) % period]).astype(np.int32))
 
         if args.h2d:
             # PCIe-inclusive mode (f2): one engine, pool = two halves of B slots; lanes of one sequence are contiguous so
@@ -172,13 +189,15 @@ def run_rank(args):
             assert E == 1
             for en in engs:
                 en.close()
-            eng = Engine(B, 2 * B, ctx=ctx, motion_distortion=not args.no_md)
+            eng = Engine(B, 2 * B, ctx=ctx, motion_distortion=not args.no_md, retrack_on_device=not args.no_retrack, retrack_slots=args.retrack_slots)
             engs = [eng]
             per = B // Dn_
             pinned = ctx.host_alloc((Dn_ * T, 400, 3779))
             for d in range(Dn_):
                 for t in range(T):
                     pinned[d * T + t] = seqs[d][0][t]
+
+            cyc = cyc_full[1:] + cyc_full[:1]
 
             def upload(step, half):
                 t = 0 if step < 0 else cyc[step % len(cyc)]
@@ -190,7 +209,10 @@ def run_rank(args):
             eng.synchronize()
             for b in range(B):
                 d = min(b // per, Dn_ - 1)
-                eng.init_lane(b, b, seqs[d][2], seqs[d][1][0])
+                if args.no_retrack:
+                    eng.init_lane(b, b, seqs[d][2], seqs[d][1][0])
+                else:
+                    eng.init_lane_detect(b, b, seqs[d][1][0])
             upload(0, 1)
 
             def step_all(i):                                   # noqa: F811
@@ -205,15 +227,33 @@ def run_rank(args):
         if comm is not None:
             comm.barrier()
 
+    # per-step records are consumed INSIDE the timed loop, two steps behind the enqueue front (result ring: waiting for step
+    # s - 2 does not drain steps s - 1 and s): every pose of every lane is read, retracks are counted as they happen
+    stat = dict(steps=0, retracks=0, tracked=0, good=0, inliers=0, overflow=0)
+
+    def consume(step):
+        if args.dry_engine or step < 0:
+            return
+        for en in engs:
+            r = en.results_array(step)
+            stat["steps"] += 1
+            stat["retracks"] += int(np.count_nonzero(r["flags"] & 8))
+            stat["overflow"] += int(np.count_nonzero((r["flags"] >> 8) & 15))
+            stat["tracked"] += int(r["n_tracked"].sum()); stat["good"] += int(r["n_good"].sum()); stat["inliers"] += int(r["n_inliers"].sum())
+
     s = 0
     for _ in range(args.warmup):
         step_all(s); s += 1
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         step_all(s); s += 1
+        if k >= 2:
+            consume(s - 3)
     barrier()
     dt = time.perf_counter() - t0
+    for k in range(max(0, args.steps - 2), args.steps):
+        consume(args.warmup + k)
     res = eng.results()
     if comm is not None:
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
@@ -230,6 +270,34 @@ def run_rank(args):
             assert got["prunedUndistortedLocals"].shape[1] == 2 and got["peaks"].shape[1] == 2 and got["lane"] == 0
         kf_ms = (time.perf_counter() - k0) * 1e3 / world
 
+    # steady vs retrack throughput beside the mix (after the timed region; single numbers of this rank)
+    extra = {}
+    if not args.dry_engine and not args.no_retrack and not args.h2d:
+        stage_mix = eng.stage_times()
+        k2 = max(3, min(10, args.steps))
+        for en in engs:
+            en.set_retrack(0)                                   # no re-detection: the steady pair
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step_all(s); s += 1
+        for en in engs:
+            en.synchronize()
+        extra["steady_pairs_per_s"] = round(B * k2 / (time.perf_counter() - t1), 1)
+        for en in engs:
+            en.set_retrack(2)                                   # every lane re-detects: the cost of a retrack pair
+        step_all(s); s += 1
+        for en in engs:
+            en.synchronize()
+        st_forced = eng.stage_times()
+        extra["retrack_stage_ms_all_lanes"] = round(st_forced["retrack"], 3)
+        extra["retrack_us_per_lane"] = round(st_forced["retrack"] * 1e3 / (B // len(engs)), 2)
+        steady_ms = B / extra["steady_pairs_per_s"] * 1e3
+        extra["retrack_pairs_per_s"] = round(B / ((steady_ms + st_forced["retrack"] * len(engs)) * 1e-3), 1)
+        for en in engs:
+            en.set_retrack(1)
+        extra["stage_ms_last_mix_step"] = {k: round(v, 4) for k, v in stage_mix.items()}
+
     out = None
     if rank == 0:
         pairs = B * args.steps * world
@@ -238,24 +306,31 @@ def run_rank(args):
             "metric": "radar scan-pairs/sec (400x3768 polar)", "value": round(value, 2), "unit": "scan-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
-            "data": f"synthetic Oxford-format 400x3779 u8 records; {Dn_} distinct seeded sequences x {T} frames per rank, replicated into {B} lane-private HBM copies, ping-pong replay",
-            "config": {"workload": "steady-state scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
-                                   + ("motion-distortion LM" if not args.no_md else "dead reckoning") + ")",
+            "data": f"synthetic Oxford-format 400x3779 u8 records; {Dn_} distinct seeded sequences x {T} frames per rank (460 static reflectors + "
+                    + ("24 movers" if args.no_retrack else "120 movers, scan-to-scan scintillation 0.6") + f"), replicated into {B} lane-private HBM copies, ping-pong replay with staggered phases",
+            "config": {"workload": "scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
+                                   + ("motion-distortion LM" if not args.no_md else "dead reckoning")
+                                   + (", keyframe bookkeeping; features host-seeded, no re-detection)" if args.no_retrack else
+                                      ", keyframe bookkeeping, DoH + ANMS re-detection on the device whenever a lane runs out of features; every lane's pose read back every step)"),
                        "lanes_per_gpu": B, "engines_per_gpu": len(engs), "h2d_streaming": bool(args.h2d), "frames": T,
                        "device": info["name"], "arch": info["arch"], "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("bench.py --gpus" if world > 1 else "single process"),
                        "collective_backend": None if comm is None else comm.backend,
                        "comm_rank_world_seen": comm_seen,
-                       "mean_tracked": round(float(np.mean([r["n_tracked"] for r in res])), 1),
-                       "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
+                       "mean_tracked": round(stat["tracked"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 1) if stat["steps"] else round(float(np.mean([r["n_tracked"] for r in res])), 1),
+                       "mean_inliers": round(stat["inliers"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 1) if stat["steps"] else round(float(np.mean([r["n_inliers"] for r in res])), 1),
+                       "rejected_fraction": round(1.0 - stat["inliers"] / max(1, stat["good"]), 4) if stat["steps"] else None,
+                       "retrack_fraction": round(stat["retracks"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 4) if stat["steps"] else None,
+                       "detect_overflows": stat["overflow"],
                        "mean_lm_nfev": round(float(np.mean([r["lm_nfev"] for r in res])), 1),
                        "keyframe_broadcast_ms": None if kf_ms is None else round(kf_ms, 3)},
             "roofline": None, "cpu_baseline": None,
         }
         if not args.dry_engine:
-            out["config"]["initial_features"] = int(np.mean([len(q[2]) for q in seqs]))
-            out["config"]["stage_ms_last_step"] = {k: round(v, 4) for k, v in eng.stage_times().items()}
+            out["config"].update(extra)
+            if not extra:
+                out["config"]["stage_ms_last_step"] = {k: round(v, 4) for k, v in eng.stage_times().items()}
             out["config"]["whole_path_Bmin_GBs_per_gpu"] = round(13.07e6 * (value / world) / 1e9, 3)   # SURVEY 8d B_min per steady pair
-            out["roofline"] = roofline(eng, args, B)
+            out["roofline"] = roofline(eng, args, B, out["config"].get("retrack_fraction") or 0.0)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, seqs, cyc)
     for en in engs:
@@ -268,28 +343,41 @@ def run_rank(args):
         print(json.dumps(out), flush=True)
 
 
-def roofline(eng, args, B):
-    """roofline of the dominant HBM-streaming kernel.  `avg_launch_ms` is the kernel's average launch duration over the K
-    timed steps, from HIP event pairs recorded on the stream it runs on (roam_engine_kernel_avg; no synchronisation inside the
-    timed region).  In the pipelined engine other kernels share the GPU during those launches, so the same kernels are also
-    re-launched alone after the timed region (roam_engine_time_kernel) and reported as `isolated_*`."""
-    names = ("ingest_peaks", "warp_quantise", "pyramid")
+def roofline(eng, args, B, retrack_fraction):
+    """roofline of the dominant HBM-streaming kernel of a step.  Candidates: the three front-end kernels (once per lane and
+    step) and the two image-scale kernels of the feature re-detection (once per RETRACKING lane: weighted by the observed
+    retrack fraction).  For the front-end kernels `avg_launch_ms` is the average launch duration over the K timed steps
+    from HIP event pairs recorded on the stream the kernel runs on (roam_engine_kernel_avg; nothing synchronises inside the
+    timed region); in the pipelined engine other kernels share the GPU during those launches, so every candidate is also
+    re-launched alone after the timed region (roam_engine_time_kernel, HIP events on its stream) = `isolated_*`."""
+    names = ["ingest_peaks", "warp_quantise", "pyramid"]
     live = {k: eng.kernel_avg(k, args.steps)[0] for k in names}
     iso = {k: eng.time_kernel(k, args.kernel_reps) for k in names}
-    dom = max(iso, key=lambda k: iso[k][0])          # dominant by its own (isolated) cost: in the pipeline the in-step
-    # durations of concurrent kernels stretch over each other and say little about which one costs most
-    ms, algo_bytes = live[dom], iso[dom][1]
+    per_step = {k: iso[k][0] for k in names}                       # ms of the kernel alone per step
+    slots = None
+    if not args.no_retrack:
+        slots = min(B, args.retrack_slots or 512)
+        for k in ("doh_integral", "doh_det_maxima"):
+            iso[k] = eng.time_kernel(k, max(1, args.kernel_reps // 3))      # one launch = `slots` detections
+            per_step[k] = iso[k][0] / slots * retrack_fraction * B
+            names.append(k)
+    dom = max(per_step, key=per_step.get)
+    algo_bytes = iso[dom][1]
+    # in-step duration: measured for the front-end kernels; the detection kernels run inside the retrack stage, whose
+    # launches are spread over chunks - their isolated duration is the one on record
+    ms = live.get(dom, iso[dom][0])
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     # HBM traffic and VALU instruction counts of that kernel from the PMC passes taken AT THIS LANE COUNT
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.py); null when no pass at this lane count is committed
     traffic, valu_frac, src = None, None, None
-    kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_wave_kernel", "pyramid": "pyr_down_wave_kernel"}[dom]
+    kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_wave_kernel", "pyramid": "pyr_down_wave_kernel",
+             "doh_integral": "rt_integ_rows_kernel", "doh_det_maxima": "rt_det_mask_kernel"}[dom]
     for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if tj.get("lanes") == B and kname in tj["kernels"]:
                 k = tj["kernels"][kname]
-                traffic = k["traffic_bytes_per_scan"] * B
+                traffic = k.get("traffic_bytes_per_launch")
                 if k.get("valu_wave_insts_per_launch"):
                     # issue-bound view: VALU wave-instructions x 4 cycles each over 1024 SIMDs, relative to the launch time alone
                     valu_frac = k["valu_wave_insts_per_launch"] * 4 / (SIMDS * CLOCK_HZ * iso[dom][0] * 1e-3)
@@ -303,7 +391,9 @@ def roofline(eng, args, B):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
             "valu_issue_frac_isolated": None if valu_frac is None else round(valu_frac, 4),
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+            "units_per_launch": slots if dom.startswith("doh") else B,
             "isolated_achieved": round(iso_frac * HBM_PEAK_GBS, 2), "isolated_frac": round(iso_frac, 5),
+            "kernel_ms_per_step_alone": {k: round(v, 4) for k, v in per_step.items()},
             "in_step_kernel_ms": {k: round(v, 4) for k, v in live.items()},
             "isolated_kernel_ms": {k: round(v[0], 4) for k, v in iso.items()},
             "isolated_kernel_GBs": {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in iso.items()}}
@@ -316,18 +406,21 @@ def cpu_baseline(args, seqs, cyc):
         return None
     import oracle
     recs, poses, feat = seqs[0]
-    P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=not args.no_md)
+    det = None if args.no_retrack else (lambda cart: oracle.getFeatures(cart)[0])
+    if det is not None:                                            # like the GPU lanes: first features detected, not given
+        feat = oracle.append_dedupe(np.empty((0, 2)), det(oracle.convertPolarImageToCartesian(recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.))))
+    P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=not args.no_md, detect=det)
     c0 = time.perf_counter()
     for n in range(args.cpu_pairs):
         P.step(recs[cyc[n % len(cyc)]])
     one = args.cpu_pairs / (time.perf_counter() - c0)
     cpu = {"value": round(one, 3), "unit": "scan-pairs/s", "cores": 1, "kind": "port",
-           "sample": f"{args.cpu_pairs} consecutive scan pairs of synthetic sequence 0 (same workload, oracle C/numpy restatement, 1 thread)"}
+           "sample": f"{args.cpu_pairs} consecutive scan pairs of synthetic sequence 0 (same workload incl. re-detections, oracle C/numpy restatement, 1 thread)"}
     nproc = args.cpu_procs if args.cpu_procs >= 0 else max(1, (os.cpu_count() or 2) // 2)
     if nproc > 1:
         import multiprocessing as mp
         per = max(8, args.cpu_pairs // 4)
-        jobs = [(5000 + i, args.frames, per, not args.no_md) for i in range(nproc)]
+        jobs = [(5000 + i, args.frames, per, not args.no_md, not args.no_retrack) for i in range(nproc)]
         with mp.get_context("spawn").Pool(nproc) as pool:
             w0 = time.perf_counter()
             done = pool.map(cpu_worker, jobs)

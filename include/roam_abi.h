@@ -219,6 +219,9 @@ int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
  * flags of step N can be consumed while steps N+1.. are still running.  ROAM_E_STATE if the step left the ring. */
 int32_t roam_engine_step_results(roam_ctx *ctx, int64_t step, roam_lane_result *out, int32_t n);
 int32_t roam_engine_steps_enqueued(roam_ctx *ctx, int64_t *nstep);
+/* device-side retrack of the following steps: 0 = suspended (flags are still raised), 1 = lanes that ran out of features
+ * (default), 2 = every lane in every step (measurement of the detection cost) */
+int32_t roam_engine_set_retrack(roam_ctx *ctx, int32_t mode);
 /* like roam_engine_init_lane, but the initial features are DETECTED on the device from the pool scan
  * (appendNewFeatures(prevImgCart, empty), RawROAMSystem.py:150); needs cfg.retrack_on_device */
 int32_t roam_engine_init_lane_detect(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const double *pose3);

@@ -77,6 +77,7 @@ _SIGS = {
     "roam_engine_results": (C.c_int32, [_vp, _P(LaneResult), C.c_int32]),
     "roam_engine_step_results": (C.c_int32, [_vp, C.c_int64, _P(LaneResult), C.c_int32]),
     "roam_engine_steps_enqueued": (C.c_int32, [_vp, _P(C.c_int64)]),
+    "roam_engine_set_retrack": (C.c_int32, [_vp, C.c_int32]),
     "roam_engine_init_lane_detect": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp]),
     "roam_engine_lane_features": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_lane_peaks": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),

@@ -82,6 +82,7 @@ struct Engine {
     bool pool_dirty = false;
     RtArgs rt;                                      // device-side retrack (retrack.hip)
     bool rt_on = false;
+    int rt_mode = 1;                                // 0 = suspended, 1 = lanes that ran out of features, 2 = every lane (measurement)
     uint8_t *kfb = nullptr;                         // 8e: packed keyframe payload (RCCL broadcast buffer)
     hipEvent_t ev[ST_COUNT + 1];
     hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
@@ -897,10 +898,10 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
                        e->map_cap);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_RETRACK], st));
-    if (e->rt_on) {
+    if (e->rt_on && e->rt_mode) {
         // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
         e->rt.res = res_slot;
-        HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt));
+        HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
         HIP_TRY(ctx, launch_retrack(st, e->rt, B));
     }
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
@@ -937,6 +938,15 @@ int32_t roam_engine_step_results(roam_ctx *ctx, int64_t step, roam_lane_result *
     const int rs = (int)(step % RES_RING);
     HIP_TRY(ctx, hipEventSynchronize(e->ev_res[rs]));      // waits for that step's records only; later steps keep running
     memcpy(out, e->results_host + (size_t)rs * e->B, sizeof(roam_lane_result) * (size_t)n);
+    return ROAM_OK;
+}
+
+int32_t roam_engine_set_retrack(roam_ctx *ctx, int32_t mode)
+{
+    ENGINE();
+    ARG_CHECK(ctx, mode >= 0 && mode <= 2);
+    if (!e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
+    e->rt_mode = mode;
     return ROAM_OK;
 }
 
@@ -1074,6 +1084,24 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[(e->pk + 1) % 3], c.peaks_cap, e->peaks_n[(e->pk + 1) % 3]);
             HIP_TRY(ctx, er);
             bytes = (double)B * ((double)c.rows * c.clip);
+        } else if (!strcmp(name, "doh_integral") || !strcmp(name, "doh_det_maxima")) {
+            // the image-scale kernels of the device-side retrack over all scratch slots (per launch: `slots` detections)
+            if (!e->rt_on) { hipEventDestroy(a); hipEventDestroy(b); ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
+            const int P = e->rt.slots, which = !strcmp(name, "doh_integral") ? 0 : 1;
+            if (r == 0) {
+                std::vector<int32_t> sc(P);
+                for (int i = 0; i < P; i++) sc[i] = e->last_scan[i % B] >= 0 ? e->last_scan[i % B] : 0;
+                HIP_TRY(ctx, hipMemcpy(e->rt.rt_scan, sc.data(), sizeof(int32_t) * (size_t)P, hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(e->rt.rt_n, &P, sizeof(int32_t), hipMemcpyHostToDevice));
+                if (which == 1) HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, 0));      // valid integral images to work on
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                HIP_TRY(ctx, hipEventRecord(a, st));
+            }
+            HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, which));
+            const double npx = (double)e->W * e->W;
+            // algorithmic bytes per detection: integral image = polar payload read + float64 image written by the column pass,
+            // read and written by the row pass; determinants + maxima = float64 image read once + 1 byte per pixel written
+            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + 3.0 * npx * 8.0) : (npx * 8.0 + npx));
         } else if (!strcmp(name, "pyramid")) {
             HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
             double rd = 0, wr = 0;

@@ -38,9 +38,10 @@ struct RtArgs {
     int32_t *sel, *sel_n;           // BP_MAX_PTS, 1
 };
 
-hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, const RtArgs &a);
+hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, int force_all, const RtArgs &a);
 // runs the detection for the rt_n flagged lanes (device count, at most B), in chunks of a.slots
 hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B);
 hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride, const int32_t *count, int kp_cap, int P,
                             int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
                             const int32_t *n_active, int first);
+hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which);

@@ -20,6 +20,7 @@
 #include "doh_common.h"
 #include "blobprune.h"
 #include "retrack.h"
+#include <algorithm>
 
 #define KS ROAM_MAX_FEATURES
 #define CART_CENTER 1012.0
@@ -28,8 +29,8 @@
 
 // ------------------------------------------------------------------------------------------------ K0: flagged lanes
 __global__ __launch_bounds__(256) void rt_collect_kernel(const roam_lane_result *__restrict__ res, const int32_t *__restrict__ scan_idx,
-                                                         int B, int32_t *__restrict__ rt_lane, int32_t *__restrict__ rt_scan,
-                                                         int32_t *__restrict__ rt_n)
+                                                         int B, int force_all, int32_t *__restrict__ rt_lane,
+                                                         int32_t *__restrict__ rt_scan, int32_t *__restrict__ rt_n)
 {
     __shared__ int sh[8];
     __shared__ int base_s;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void rt_collect_kernel(const roam_lane_result 
     __syncthreads();
     for (int b0 = 0; b0 < B; b0 += 256) {
         const int b = b0 + t;
-        const int f = (b < B && (res[b].flags & 4)) ? 1 : 0;
+        const int f = (b < B && (force_all || (res[b].flags & 4))) ? 1 : 0;
         // block exclusive scan
         const int lane = t & 63, w = t >> 6;
         int inc = f;
@@ -122,14 +123,19 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 // ------------------------------------------------------------------------------------------------ K3: determinants + maxima
 #define RT_TH 16
 #define RT_TW 64
-__global__ __launch_bounds__(256) void rt_det_mask_kernel(RtArgs a, int first)
+__global__ __launch_bounds__(256) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
 {
     __shared__ double det[2][RT_TH + 2][RT_TW + 2];
-    const int ls = blockIdx.z, slot = first + ls;
-    if (slot >= *a.rt_n) return;
+    // persistent-style grid: the number of live slots is known only on the device, and two million empty workgroups per
+    // chunk cost more to dispatch than the whole tracking step
+    const int nact = min(P, max(0, *a.rt_n - first));
+    const int per = tiles_x * tiles_y;
+    for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
+    const int ls = work / per, trem = work - ls * per;
     const int W = a.W, H = a.W;
     const double *S = a.S + (int64_t)ls * W * W;
-    const int r0 = blockIdx.y * RT_TH, c0 = blockIdx.x * RT_TW, t = threadIdx.x;
+    const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW, t = threadIdx.x;
+    __syncthreads();
     // outside the image the 3x3x3 footprint sees nothing that could exceed v (mode = 'constant', 0 < threshold < v)
     for (int i = t; i < 2 * (RT_TH + 2) * (RT_TW + 2); i += 256) {
         const int l = i / ((RT_TH + 2) * (RT_TW + 2)), rem = i - l * ((RT_TH + 2) * (RT_TW + 2));
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(256) void rt_det_mask_kernel(RtArgs a, int first)
         }
         a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
         if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
+    }
     }
 }
 
@@ -427,7 +434,11 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
-        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((W + RT_TW - 1) / RT_TW, (W + RT_TH - 1) / RT_TH, P), dim3(256), 0, st, a, first);
+        {
+            const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
+            const int64_t all = (int64_t)tx * ty * P;
+            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(256), 0, st, a, first, P, tx, ty);
+        }
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
         e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, P, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, first);
@@ -439,9 +450,27 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
     return hipSuccess;
 }
 
-hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, const RtArgs &a)
+hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, int force_all, const RtArgs &a)
 {
-    hipLaunchKernelGGL(rt_collect_kernel, dim3(1), dim3(256), 0, st, res, scan_idx, B, a.rt_lane, a.rt_scan, a.rt_n);
+    hipLaunchKernelGGL(rt_collect_kernel, dim3(1), dim3(256), 0, st, res, scan_idx, B, force_all, a.rt_lane, a.rt_scan, a.rt_n);
+    return hipGetLastError();
+}
+
+// measurement: re-run the image-scale kernels of the detection for the first `P` scratch slots (their integral images are
+// those of the last retracks; rt_n is set by the caller); which: 0 = integral image (cols + rows), 1 = determinants + maxima
+hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which)
+{
+    const int W = a.W;
+    if (which == 0) {
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, 0);
+    } else {
+        hipError_t e = hipMemsetAsync(a.row_cnt, 0, sizeof(int32_t) * (size_t)P * (W + 1), st);
+        if (e != hipSuccess) return e;
+        const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
+        const int64_t all = (int64_t)tx * ty * P;
+        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(256), 0, st, a, 0, P, tx, ty);
+    }
     return hipGetLastError();
 }
 

@@ -101,6 +101,10 @@ class Engine:
     def synchronize(self):
         self.ctx.check(self.lib.roam_synchronize(self.ctx.h))
 
+    def set_retrack(self, mode: int):
+        """0 = suspended, 1 = lanes that ran out of features (default), 2 = every lane every step (measurement)"""
+        self.ctx.check(self.lib.roam_engine_set_retrack(self.ctx.h, int(mode)))
+
     def steps_enqueued(self) -> int:
         n = C.c_int64(0)
         self.ctx.check(self.lib.roam_engine_steps_enqueued(self.ctx.h, C.byref(n)))

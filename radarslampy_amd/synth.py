@@ -55,11 +55,17 @@ def _speckle(rng, rows, cols, mean=9.0):
     return n
 
 
-def render_record(world: World, pose, t_index: int = 0, velocity=None, seed: int = 0, timestamp_us: int = 1547131046353776):
+def render_record(world: World, pose, t_index: int = 0, velocity=None, seed: int = 0, timestamp_us: int = 1547131046353776,
+                  scintillation: float = 0.0):
     """One 400 x 3779 u8 record of `world` seen from `pose`.  velocity=(vx,vy,vth) [m/s,rad/s]
-    switches the intra-scan motion distortion on."""
+    switches the intra-scan motion distortion on.  scintillation in (0, 1]: every reflector's amplitude is scaled by an
+    independent factor in [1 - scintillation, 1] per frame (radar returns fluctuate from scan to scan; on the real `tiny`
+    scans half of the tracked features fail the LK error gate every frame)."""
     rng = np.random.default_rng((world.seed * 1000003 + t_index * 7 + seed) & 0x7fffffff)
     img = _speckle(rng, ROWS, NBINS)
+    fade = np.ones(len(world.amp))
+    if scintillation > 0:
+        fade = np.random.default_rng((world.seed * 7919 + t_index * 104729 + 13) & 0x7fffffff).uniform(1.0 - scintillation, 1.0, size=len(world.amp))
     Tinv = np.linalg.inv(se2(*pose))
     pts = world.static
     if len(world.movers):
@@ -75,7 +81,7 @@ def render_record(world: World, pose, t_index: int = 0, velocity=None, seed: int
     r = np.hypot(p[:, 0], p[:, 1]) / RANGE_RES
     az = (np.arctan2(p[:, 1], p[:, 0]) % (2 * np.pi)) * ROWS / (2 * np.pi)
     rows_idx = np.arange(ROWS)[:, None]
-    for ri, ai, A in zip(r, az, world.amp):
+    for ri, ai, A in zip(r, az, world.amp * fade):
         if ri < 20 or ri > NBINS - 20:
             continue
         sig_a = max(0.9, 2.2 * ROWS / (2 * np.pi * max(ri * 0.5, 1.0)) * 4.0)   # ~constant metric extent
@@ -108,7 +114,8 @@ def reflector_pixels(world: World, pose, margin_px: float = 40.0):
     return px[keep].astype(np.float32)
 
 
-def make_sequence(seed: int, n_frames: int, n_static: int = 320, n_movers: int = 0, distortion: bool = False):
+def make_sequence(seed: int, n_frames: int, n_static: int = 320, n_movers: int = 0, distortion: bool = False,
+                  scintillation: float = 0.0):
     """-> (records list of (400,3779) u8, poses (n,3), initial features (K,2) f32)."""
     world = World(seed, n_static, n_movers)
     poses = trajectory(n_frames, seed)
@@ -118,5 +125,5 @@ def make_sequence(seed: int, n_frames: int, n_static: int = 320, n_movers: int =
         if distortion and t > 0:
             d = np.linalg.inv(se2(*poses[t - 1])) @ se2(*poses[t])
             vel = np.array([d[0, 2], d[1, 2], np.arctan2(d[1, 0], d[0, 0])]) / 0.25
-        recs.append(render_record(world, poses[t], t, vel))
+        recs.append(render_record(world, poses[t], t, vel, scintillation=scintillation))
     return recs, poses, reflector_pixels(world, poses[0])
