@@ -1,37 +1,76 @@
 // doh_common.h - device functions shared by the stage-level DoH kernels (doh.hip) and the engine's retrack (retrack.hip):
 // the box-filter Hessian determinant of skimage's _hessian_matrix_det, operation by operation (oracle/c/doh.c).
+// The integral image is read through an accessor so that the same arithmetic runs on global memory (indices clipped at
+// the image border like skimage's _integ) and on a tile staged in LDS (interior tiles: nothing to clip).
 #pragma once
 #include "roam_internal.h"
 
 __device__ __forceinline__ int clipi(int x, int lo, int hi) { return x > hi ? hi : (x < lo ? lo : x); }
-__device__ __forceinline__ double integ(const double *__restrict__ S, int H, int W, int r, int c, int rl, int cl)
+
+struct DohGlobalAcc {
+    const double *__restrict__ S; int H, W;
+    __device__ __forceinline__ int cr(int r) const { return clipi(r, 0, H - 1); }
+    __device__ __forceinline__ int cc(int c) const { return clipi(c, 0, W - 1); }
+    __device__ __forceinline__ double at(int r, int c) const { return S[(int64_t)r * W + c]; }
+};
+
+struct DohGlobalInteriorAcc {            // interior pixels: no index leaves the image
+    const double *__restrict__ S; int W;
+    __device__ __forceinline__ int cr(int r) const { return r; }
+    __device__ __forceinline__ int cc(int c) const { return c; }
+    __device__ __forceinline__ double at(int r, int c) const { return S[r * W + c]; }
+};
+
+template <int PITCH>
+struct DohLdsAcc {                       // rows rbase.., columns cbase.. of the integral image, staged by the caller
+    const double *blk; int rbase, cbase;
+    __device__ __forceinline__ int cr(int r) const { return r; }
+    __device__ __forceinline__ int cc(int c) const { return c; }
+    __device__ __forceinline__ double at(int r, int c) const { return blk[(r - rbase) * PITCH + (c - cbase)]; }
+};
+
+template <typename ACC>
+__device__ __forceinline__ double integ_acc(const ACC &a, int r, int c, int rl, int cl)
 {
-    r = clipi(r, 0, H - 1);
-    c = clipi(c, 0, W - 1);
-    const int r2 = clipi(r + rl, 0, H - 1), c2 = clipi(c + cl, 0, W - 1);
-    const double ans = __dsub_rn(__dsub_rn(__dadd_rn(S[(int64_t)r * W + c], S[(int64_t)r2 * W + c2]), S[(int64_t)r * W + c2]),
-                                 S[(int64_t)r2 * W + c]);
-    return ans < 0 ? 0 : ans;
+    r = a.cr(r);
+    c = a.cc(c);
+    const int r2 = a.cr(r + rl), c2 = a.cc(c + cl);
+    const double ans = __dsub_rn(__dsub_rn(__dadd_rn(a.at(r, c), a.at(r2, c2)), a.at(r, c2)), a.at(r2, c));
+    return fmax(ans, 0.0);       // skimage: max(0, ans); one v_max_f64 (a -0.0 result may come out as +0.0: no comparison or sum downstream can tell)
 }
 
 // determinant of the approximated Hessian at (r, c) for box size `size` = int(3 * sigma)
-__device__ __forceinline__ double hessian_det_at(const double *__restrict__ S, int H, int W, int size, int r, int c)
+template <typename ACC>
+__device__ __forceinline__ double hessian_det_acc(const ACC &a, int size, int r, int c)
 {
     const int s2 = (size - 1) / 2, s3 = size / 3, w = size;
     const double w_i = __ddiv_rn(__ddiv_rn(1.0, (double)size), (double)size);
-    const double tl = integ(S, H, W, r - s3, c - s3, s3, s3);
-    const double br = integ(S, H, W, r + 1, c + 1, s3, s3);
-    const double bl = integ(S, H, W, r - s3, c + 1, s3, s3);
-    const double tr = integ(S, H, W, r + 1, c - s3, s3, s3);
+    const double tl = integ_acc(a, r - s3, c - s3, s3, s3);
+    const double br = integ_acc(a, r + 1, c + 1, s3, s3);
+    const double bl = integ_acc(a, r - s3, c + 1, s3, s3);
+    const double tr = integ_acc(a, r + 1, c - s3, s3, s3);
     double dxy = __dsub_rn(__dsub_rn(__dadd_rn(bl, tr), tl), br);
     dxy = __dmul_rn(-dxy, w_i);
-    double mid = integ(S, H, W, r - s3 + 1, c - s2, 2 * s3 - 1, w);
-    double side = integ(S, H, W, r - s3 + 1, c - s3 / 2, 2 * s3 - 1, s3);
+    double mid = integ_acc(a, r - s3 + 1, c - s2, 2 * s3 - 1, w);
+    double side = integ_acc(a, r - s3 + 1, c - s3 / 2, 2 * s3 - 1, s3);
     double dxx = __dsub_rn(mid, __dmul_rn(3.0, side));
     dxx = __dmul_rn(-dxx, w_i);
-    mid = integ(S, H, W, r - s2, c - s3 + 1, w, 2 * s3 - 1);
-    side = integ(S, H, W, r - s3 / 2, c - s3 + 1, s3, 2 * s3 - 1);
+    mid = integ_acc(a, r - s2, c - s3 + 1, w, 2 * s3 - 1);
+    side = integ_acc(a, r - s3 / 2, c - s3 + 1, s3, 2 * s3 - 1);
     double dyy = __dsub_rn(mid, __dmul_rn(3.0, side));
     dyy = __dmul_rn(-dyy, w_i);
     return __dsub_rn(__dmul_rn(dxx, dyy), __dmul_rn(0.81, __dmul_rn(dxy, dxy)));
+}
+
+// compile-time box size: every corner offset folds into the load instruction's immediate (LDS tiles: one base address per pixel)
+template <int SIZE, typename ACC>
+__device__ __forceinline__ double hessian_det_fixed(const ACC &a, int r, int c)
+{
+    return hessian_det_acc(a, SIZE, r, c);
+}
+
+__device__ __forceinline__ double hessian_det_at(const double *__restrict__ S, int H, int W, int size, int r, int c)
+{
+    const DohGlobalAcc a = {S, H, W};
+    return hessian_det_acc(a, size, r, c);
 }

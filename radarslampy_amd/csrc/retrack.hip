@@ -70,51 +70,70 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
     double *S = a.S + (int64_t)ls * W * W;
     const int rows = a.rows, cols = a.cols, stride = a.stride;
     double acc = 0;
-    for (int r = 0; r < W; r++) {
-        const uint32_t m = a.map[(int64_t)r * W + c];
+    auto pixel = [&](uint32_t m) -> float {              // the arithmetic of warp_gather_kernel's direct path (= warp_pixel)
         const int ix = m & 4095, iy = (m >> 12) & 1023;
-        float v = 0.f;
-        if (ix < cols) {                                 // the arithmetic of warp_gather_kernel's direct path (= warp_pixel)
-            const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
-            const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
-            int r0 = iy - 1, r1 = iy;
-            if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
-            if (r1 >= rows) r1 -= rows;
-            const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
-            const bool i1 = ix + 1 < cols;
-            const float s00 = rt_code_to_f32(q0[0]), s01 = i1 ? rt_code_to_f32(q0[1]) : 0.f;
-            const float s10 = rt_code_to_f32(q1[0]), s11 = i1 ? rt_code_to_f32(q1[1]) : 0.f;
-            v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
-            v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
-            v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
-            v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
-        }
-        acc = __dadd_rn(acc, (double)v);
-        S[(int64_t)r * W + c] = acc;
+        if (ix >= cols) return 0.f;
+        const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+        const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+        int r0 = iy - 1, r1 = iy;
+        if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
+        if (r1 >= rows) r1 -= rows;
+        const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
+        const bool i1 = ix + 1 < cols;
+        const float s00 = rt_code_to_f32(q0[0]), s01 = i1 ? rt_code_to_f32(q0[1]) : 0.f;
+        const float s10 = rt_code_to_f32(q1[0]), s11 = i1 ? rt_code_to_f32(q1[1]) : 0.f;
+        float v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
+        v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
+        v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
+        v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
+        return v;
+    };
+    // four rows per iteration: their map words and taps are independent loads, only the four additions are a chain
+    int r = 0;
+    for (; r + 4 <= W; r += 4) {
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = a.map[(int64_t)(r + k) * W + c];
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = pixel(m[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { acc = __dadd_rn(acc, (double)v[k]); S[(int64_t)(r + k) * W + c] = acc; }
     }
+    for (; r < W; r++) { acc = __dadd_rn(acc, (double)pixel(a.map[(int64_t)r * W + c])); S[(int64_t)r * W + c] = acc; }
 }
 
+// one wavefront per 64 rows: lane = row, sequential along the row (the reference's summation order); the image streams
+// through LDS in 64 x RT_CW tiles so that global accesses stay coalesced (a lane of the load covers RT_CW / 16 rows x 16 B)
+#ifndef RT_CW
+#define RT_CW 32
+#endif
 __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 {
-    __shared__ double tile[64][65];
+    __shared__ double tile[64][RT_CW + 1];
     const int ls = blockIdx.y, slot = first + ls;
     if (slot >= *a.rt_n) return;
     const int W = a.W, H = a.W;
     double *S = a.S + (int64_t)ls * W * W;
     const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+    constexpr int RPI = 64 / RT_CW;                     // rows per load instruction
+    const int lr = lane / RT_CW, lc = lane % RT_CW;
     double acc = 0;
-    for (int c0 = 0; c0 < W; c0 += 64) {
-        for (int k = 0; k < 64; k++) {
-            const int r = r0 + k, c = c0 + lane;
-            tile[k][lane] = (r < H && c < W) ? S[(int64_t)r * W + c] : 0.0;
+    for (int c0 = 0; c0 < W; c0 += RT_CW) {
+        const int c = c0 + lc;
+#pragma unroll 8
+        for (int k = 0; k < 64; k += RPI) {
+            const int r = r0 + k + lr;
+            tile[k + lr][lc] = (r < H && c < W) ? S[(int64_t)r * W + c] : 0.0;
         }
         __syncthreads();
-        const int nc = min(64, W - c0);
+        const int nc = min(RT_CW, W - c0);
         for (int j = 0; j < nc; j++) { acc = __dadd_rn(acc, tile[lane][j]); tile[lane][j] = acc; }
         __syncthreads();
-        for (int k = 0; k < 64; k++) {
-            const int r = r0 + k, c = c0 + lane;
-            if (r < H && c < W) S[(int64_t)r * W + c] = tile[k][lane];
+#pragma unroll 8
+        for (int k = 0; k < 64; k += RPI) {
+            const int r = r0 + k + lr;
+            if (r < H && c < W) S[(int64_t)r * W + c] = tile[k + lr][lc];
         }
         __syncthreads();
     }
@@ -123,7 +142,11 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 // ------------------------------------------------------------------------------------------------ K3: determinants + maxima
 #define RT_TH 16
 #define RT_TW 64
-__global__ __launch_bounds__(256) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
+#define RT_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
+#define RT_BR (RT_TH + 2 + 14 + 16)        // 48 rows: offsets -14 .. +16 around the 18 determinant rows
+#define RT_BC (RT_TW + 2 + 14 + 16)        // 96 columns
+#define RT_DET_THREADS 256
+__global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
 {
     __shared__ double det[2][RT_TH + 2][RT_TW + 2];
     // persistent-style grid: the number of live slots is known only on the device, and two million empty workgroups per
@@ -136,34 +159,47 @@ __global__ __launch_bounds__(256) void rt_det_mask_kernel(RtArgs a, int first, i
     const double *S = a.S + (int64_t)ls * W * W;
     const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW, t = threadIdx.x;
     __syncthreads();
+    // the 18 x 66 determinants of a tile read the integral image at rows r0-15 .. r0+32 and columns c0-15 .. c0+80 (box size
+    // 30: offsets -14 .. +16).  Staging that 48 x 96 block in LDS was measured and rejected: 150 us per detection at 2 and at 4
+    // waves per SIMD against 142 us for L1 reads at full occupancy
+    const bool interior = r0 >= RT_HALO && r0 - RT_HALO + RT_BR <= H && c0 >= RT_HALO && c0 - RT_HALO + RT_BC <= W && a.size1 == 15 && a.size2 == 30;
     // outside the image the 3x3x3 footprint sees nothing that could exceed v (mode = 'constant', 0 < threshold < v)
-    for (int i = t; i < 2 * (RT_TH + 2) * (RT_TW + 2); i += 256) {
-        const int l = i / ((RT_TH + 2) * (RT_TW + 2)), rem = i - l * ((RT_TH + 2) * (RT_TW + 2));
-        const int rr = rem / (RT_TW + 2), cc = rem - rr * (RT_TW + 2);
-        const int r = r0 + rr - 1, c = c0 + cc - 1;
-        double v = 0.0;
-        if (r >= 0 && r < H && c >= 0 && c < W) v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
-        det[l][rr][cc] = v;
+    {
+        // 2 x 18 x 66 = 2376 (layer, row, column) items over the workgroup: 9.3 per thread
+        constexpr int NPOS = (RT_TH + 2) * (RT_TW + 2);
+        int l = t / NPOS, rem = t - l * NPOS;
+        int rr = rem / (RT_TW + 2), cc = rem - rr * (RT_TW + 2);
+        for (int i = t; i < 2 * NPOS; i += RT_DET_THREADS) {
+            const int r = r0 + rr - 1, c = c0 + cc - 1;
+            double v = 0.0;
+            if (r >= 0 && r < H && c >= 0 && c < W) {
+                // interior tiles: compile-time box sizes (15, 30) and no index clipping - the box weights 1/size^2 (two float64
+                // divisions in the general form) and every corner offset fold into constants
+                if (interior) { const DohGlobalInteriorAcc ga = {S, W}; v = l == 0 ? hessian_det_fixed<15>(ga, r, c) : hessian_det_fixed<30>(ga, r, c); }
+                else v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
+            }
+            det[l][rr][cc] = v;
+            rr += RT_DET_THREADS / (RT_TW + 2); cc += RT_DET_THREADS % (RT_TW + 2);
+            if (cc >= RT_TW + 2) { cc -= RT_TW + 2; rr++; }
+            if (rr >= RT_TH + 2) { rr -= RT_TH + 2; l++; }
+        }
     }
     __syncthreads();
     const int cc = t & 63, rb = t >> 6;
-    for (int k = 0; k < RT_TH / 4; k++) {
-        const int rr = rb * (RT_TH / 4) + k, r = r0 + rr, c = c0 + cc;
+    for (int k = 0; k < RT_TH / (RT_DET_THREADS / 64); k++) {
+        const int rr = rb * (RT_TH / (RT_DET_THREADS / 64)) + k, r = r0 + rr, c = c0 + cc;
         if (r >= H || c >= W) continue;
-        uint32_t bits = 0;
+        // 3x3x3 footprint = the 18 determinants around the pixel in both layers: one maximum, loaded without branches
+        // (a short-circuit chain of 36 dependent LDS reads per pixel was 3/4 of this kernel's time)
+        double m = det[0][rr][cc];
 #pragma unroll
-        for (int l = 0; l < 2; l++) {
-            const double v = det[l][rr + 1][cc + 1];
-            if (!(v > a.threshold)) continue;
-            bool ok = true;
+        for (int ll = 0; ll < 2; ll++)
 #pragma unroll
-            for (int ll = 0; ll < 2; ll++)
+            for (int dr = 0; dr < 3; dr++)
 #pragma unroll
-                for (int dr = 0; dr < 3; dr++)
-#pragma unroll
-                    for (int dc = 0; dc < 3; dc++) ok = ok && !(det[ll][rr + dr][cc + dc] > v);
-            if (ok) bits |= 1u << l;
-        }
+                for (int dc = 0; dc < 3; dc++) { const double u = det[ll][rr + dr][cc + dc]; m = u > m ? u : m; }
+        const double v0 = det[0][rr + 1][cc + 1], v1 = det[1][rr + 1][cc + 1];
+        const uint32_t bits = ((v0 > a.threshold && !(m > v0)) ? 1u : 0u) | ((v1 > a.threshold && !(m > v1)) ? 2u : 0u);
         a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
         if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
     }
@@ -437,7 +473,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
         {
             const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
             const int64_t all = (int64_t)tx * ty * P;
-            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(256), 0, st, a, first, P, tx, ty);
+            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
         }
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
@@ -469,7 +505,7 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
         if (e != hipSuccess) return e;
         const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
         const int64_t all = (int64_t)tx * ty * P;
-        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(256), 0, st, a, 0, P, tx, ty);
+        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(RT_DET_THREADS), 0, st, a, 0, P, tx, ty);
     }
     return hipGetLastError();
 }
