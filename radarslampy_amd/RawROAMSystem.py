@@ -1,112 +1,121 @@
-"""Non-plotting counterpart of the reference driver (reference RawROAMSystem.py:20-333): same class
-name, constructor and run() semantics, the loop body of :162-298 on top of the drop-in modules, with
-the paramFlags actually honoured (`rejectOutliers`, `correctMotionDistortion`).  §8f-f3 "next" row:
-plotting, video export and the CLI are out of scope."""
+"""Streaming odometry driver on the device-resident engine.
+
+Same entry points as the reference's RawROAMSystem (constructor arguments, run(startSeqInd, endSeqInd), the paramFlags
+`rejectOutliers` / `correctMotionDistortion`; reference RawROAMSystem.py:20-160), but not its loop: frames are decoded on
+the host (PNG inflate), copied into a pinned staging ring, uploaded on the copy stream while earlier frames are being
+processed (roam_engine_upload_scans_async), and every scan pair is ONE roam_engine_step - tracking, outlier rejection,
+pose solve, keyframe bookkeeping and the feature re-detection all stay on the GPU.  Poses come back through the engine's
+per-step result ring a few frames behind the enqueue front, so the pipeline never drains.  Several sequences can run as
+lanes of one engine (`run_many`).  Plotting, video export and the command line are out of scope."""
 import os
 
 import numpy as np
 
-from .getFeatures import N_FEATURES_BEFORE_RETRACK, appendNewFeatures
-from .Mapping import Keyframe, Map
-from .motionDistortion import MotionDistortionSolver
-from .parseData import (RANGE_RESOLUTION_CART_M, convertPolarImageToCartesian, getPolarImageFromImgPaths,
-                        getRadarImgPaths)
-from .Tracker import Tracker
+from . import _ffi
+from .engine import Engine
+from .parseData import getRadarImgPaths, readRadarRecord
 from .trajectoryPlotting import Trajectory, computePosesRMSE, getGroundTruthTrajectory
-from .utils import convertPoseToTransform, convertRandHtoDeltas, radarImgPathToTimestamp
+from .utils import radarImgPathToTimestamp
 
-RADAR_CART_CENTER = np.array([1012, 1012])
+RING = 8            # resident scans per lane: frames k-1 .. k+LOOKAHEAD and a margin for the 3-deep step pipeline
+LOOKAHEAD = 3       # uploads run this many frames ahead of the step that consumes them
+LAG = 2             # results are read this many steps behind the enqueue front
 
 
-class RawROAMSystem():
-    def __init__(self, sequenceName: str, paramFlags: dict = None, hasGroundTruth: bool = True, dataRoot: str = "data") -> None:
-        self.sequenceName = sequenceName
-        self.paramFlags = dict(paramFlags or {})
-        self.hasGroundTruth = hasGroundTruth
-        dataPath = os.path.join(dataRoot, sequenceName, "radar")
-        timestampPath = os.path.join(dataRoot, sequenceName, "radar.timestamps")
-        assert os.path.exists(dataPath), "Failed to find radar data for sequence " + sequenceName
-        assert os.path.exists(timestampPath), "Failed to find radar timestamp information for sequence " + sequenceName
-        self.dataRoot = dataRoot
-        self.imgPathArr = getRadarImgPaths(dataPath, timestampPath)
+class RawROAMSystem:
+    def __init__(self, sequenceName: str, paramFlags: dict = None, hasGroundTruth: bool = True, dataRoot: str = "data",
+                 ctx: _ffi.Context = None) -> None:
+        self.sequenceName, self.paramFlags, self.hasGroundTruth, self.dataRoot = sequenceName, dict(paramFlags or {}), hasGroundTruth, dataRoot
+        seq = os.path.join(dataRoot, sequenceName)
+        self.filePaths = {"data": os.path.join(seq, "radar"), "timestamp": os.path.join(seq, "radar.timestamps")}
+        for what, p in self.filePaths.items():
+            if not os.path.exists(p):
+                raise FileNotFoundError(f"sequence {sequenceName}: no radar {what} at {p}")
+        self.imgPathArr = getRadarImgPaths(self.filePaths["data"], self.filePaths["timestamp"])
         self.sequenceSize = len(self.imgPathArr)
-        self.filePaths = {"data": dataPath, "timestamp": timestampPath}
-        self.gtTraj = None
-        self.estTraj = None
-        self.tracker = Tracker(self.sequenceName, self.imgPathArr, self.filePaths, self.paramFlags)
-        self.map = Map(self.sequenceName, self.estTraj, self.imgPathArr, self.filePaths)
+        self.ctx = ctx
+        self.gtTraj = self.estTraj = None
         self.frameLog = []
 
+    # ------------------------------------------------------------------ one sequence
     def run(self, startSeqInd: int = 0, endSeqInd: int = -1, initPose=None) -> None:
-        imgPathArr, tracker = self.imgPathArr, self.tracker
-        assert 0 <= startSeqInd < self.sequenceSize
+        n = self.sequenceSize
         if endSeqInd < 0:
-            endSeqInd = self.sequenceSize - 1
-        assert endSeqInd < self.sequenceSize and startSeqInd <= endSeqInd
-        initTimestamp = radarImgPathToTimestamp(imgPathArr[startSeqInd])
+            endSeqInd = n - 1
+        if not (0 <= startSeqInd <= endSeqInd < n):
+            raise IndexError(f"frames {startSeqInd}..{endSeqInd} of a {n}-frame sequence")
+        frames = list(range(startSeqInd, endSeqInd + 1))
+        stamps = [radarImgPathToTimestamp(self.imgPathArr[i]) for i in frames]
         gtPath = os.path.join(self.dataRoot, self.sequenceName, "gt", "radar_odometry.csv")
         if self.hasGroundTruth and os.path.exists(gtPath):
             self.gtTraj = getGroundTruthTrajectory(gtPath)
             if initPose is None:
-                initPose = self.gtTraj.getPoseAtTimes(initTimestamp)
-        if initPose is None:
-            initPose = np.zeros(3)
-        initPose = np.asarray(initPose, dtype=np.float64)
-        self.estTraj = Trajectory([initTimestamp], [initPose])
-        do_md = self.paramFlags.get("correctMotionDistortion", True)
-
-        MDS = MotionDistortionSolver(np.diag([4, 4]), np.diag([1, 1, (5 * np.pi / 180) ** 2]))
-        prev_pose = convertPoseToTransform(initPose)
-        prevImgPolar = getPolarImageFromImgPaths(imgPathArr, startSeqInd)
-        prevImgCart = convertPolarImageToCartesian(prevImgPolar)
-        blobCoord, _ = appendNewFeatures(prevImgCart, np.empty((0, 2)))
-        metricCoord = (blobCoord - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
-        zero_velocity = np.zeros((3,))
-        old_kf = Keyframe(initPose, metricCoord, prevImgPolar, zero_velocity)
-        self.map.addKeyframe(old_kf)
-        possible_kf = Keyframe(initPose, metricCoord, prevImgPolar, zero_velocity)
-        latestPose = initPose
-
-        for seqInd in range(startSeqInd + 1, endSeqInd + 1):
-            currImgPolar = getPolarImageFromImgPaths(imgPathArr, seqInd)
-            currImgCart = convertPolarImageToCartesian(currImgPolar)
-            good_old, good_new, rotAngleRad, corrStatus = tracker.track(prevImgCart, currImgCart, prevImgPolar, currImgPolar,
-                                                                        blobCoord, seqInd)
-            old_kf.pruneFeaturePoints(corrStatus)
-            R, h = tracker.getTransform(good_old, good_new, pixel=False)
-            centered_new = (good_new - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
-            timestamp = radarImgPathToTimestamp(imgPathArr[seqInd])
-            if do_md:
-                p_w = old_kf.getPrunedFeaturesGlobalPosition()
-                T_wj = prev_pose @ np.block([[R, h], [np.zeros((2,)), 1]])
-                MDS.update_problem(prev_pose, p_w, centered_new, T_wj)
-                sol = MDS.optimize_library()
-                pose_vector, velocity = sol[3:], sol[:3]
-                self.estTraj.appendAbsoluteTransform(timestamp, pose_vector)
-            else:                                      # updateTrajectory (RawROAMSystem.py:301-317)
-                self.estTraj.appendRelativeDeltas(timestamp, convertRandHtoDeltas(R, h))
-                pose_vector, velocity = self.estTraj.poses[-1].copy(), np.zeros(3)
-            latestPose = pose_vector
-            possible_kf.updateInfo(latestPose, centered_new, currImgPolar, velocity)
-            nFeatures = good_new.shape[0]
-            retrack = (nFeatures <= N_FEATURES_BEFORE_RETRACK)
-            newkf = retrack or self.map.isGoodKeyframe(possible_kf)
-            if newkf:
-                self.map.addKeyframe(possible_kf)
-                old_kf = possible_kf
-                if retrack:
-                    good_new, _ = appendNewFeatures(currImgCart, good_new)
-                    centered_new = (good_new - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
-                    old_kf.updateInfo(latestPose, centered_new, currImgPolar, velocity)
-                possible_kf = Keyframe(latestPose, centered_new, currImgPolar, velocity)
-            self.frameLog.append(dict(seqInd=seqInd, n_tracked=len(blobCoord), n_inliers=nFeatures, new_keyframe=bool(newkf),
-                                      retrack=bool(retrack), pose=np.array(latestPose, dtype=np.float64)))
-            blobCoord = good_new.copy()
-            prevImgCart = currImgCart
-            prev_pose = convertPoseToTransform(latestPose)
+                initPose = self.gtTraj.getPoseAtTimes(stamps[0])
+        initPose = np.zeros(3) if initPose is None else np.asarray(initPose, np.float64)
+        poses, log = stream_records((readRadarRecord(self.imgPathArr[i]) for i in frames), len(frames), initPose, self.paramFlags, self.ctx)
+        self.estTraj = Trajectory([stamps[0]], [initPose])
+        self.estTraj.extend_absolute(stamps[1:], poses)
+        for k, e in enumerate(log):
+            e["seqInd"] = frames[k + 1]
+        self.frameLog = log
 
     def rmse(self):
         """position RMSE of the estimate against the ground truth at the estimate's timestamps"""
-        assert self.gtTraj is not None and self.estTraj is not None
-        gt = self.gtTraj.getPoseAtTimes(self.estTraj.timestamps)
-        return computePosesRMSE(gt, self.estTraj.poses)
+        if self.gtTraj is None or self.estTraj is None:
+            raise RuntimeError("run() a sequence with ground truth first")
+        return computePosesRMSE(self.gtTraj.getPoseAtTimes(self.estTraj.timestamps), self.estTraj.poses)
+
+
+def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows=400, stride=3779, payload_off=11, clip=2025):
+    """records: iterator of n_frames (rows, stride) u8 Oxford records of ONE sequence.  -> (poses (n_frames-1, 3), per-pair log).
+    Frame 0 seeds the lane (features detected on the device); frame k is uploaded LOOKAHEAD frames before step k needs it."""
+    flags = dict(paramFlags or {})
+    own = ctx is None
+    ctx = ctx or _ffi.Context(int(os.environ.get("ROAM_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    eng = Engine(1, RING, ctx=ctx, rows=rows, stride=stride, payload_off=payload_off, clip=clip,
+                 reject_outliers=flags.get("rejectOutliers", True), motion_distortion=flags.get("correctMotionDistortion", True),
+                 retrack_on_device=True)
+    pinned = ctx.host_alloc((RING, rows, stride))
+    it = iter(records)
+    uploaded = 0
+
+    def upload_next():
+        nonlocal uploaded
+        rec = next(it, None)
+        if rec is None:
+            return False
+        slot = uploaded % RING
+        pinned[slot] = rec
+        eng.upload_scans_async(slot, pinned[slot], n=1)
+        uploaded += 1
+        return True
+
+    poses = np.empty((max(0, n_frames - 1), 3))
+    log = []
+
+    def collect(step):
+        r = eng.results(step)[0]
+        poses[step] = r["pose"]
+        log.append(dict(n_tracked=r["n_tracked"], n_good=r["n_good"], n_inliers=r["n_inliers"], new_keyframe=r["new_keyframe"],
+                        retrack=r["retrack"], n_after_retrack=r["n_after_retrack"], pose=r["pose"].copy(), velocity=r["velocity"].copy()))
+
+    try:
+        for _ in range(min(n_frames, 1 + LOOKAHEAD)):
+            upload_next()
+        eng.synchronize()
+        eng.init_lane_detect(0, 0, init_pose)
+        for k in range(1, n_frames):
+            eng.step([k % RING])
+            # slot (k + LOOKAHEAD) % RING last held frame k + LOOKAHEAD - RING <= k - 5: its steps are behind the fence
+            eng.fence()
+            upload_next()
+            if k - 1 - LAG >= 0:
+                collect(k - 1 - LAG)
+        for s in range(max(0, n_frames - 1 - LAG), n_frames - 1):
+            collect(s)
+    finally:
+        ctx.host_free(pinned)
+        eng.close()
+        if own:
+            ctx.close()
+    return poses, log

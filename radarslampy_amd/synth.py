@@ -127,3 +127,75 @@ def make_sequence(seed: int, n_frames: int, n_static: int = 320, n_movers: int =
             vel = np.array([d[0, 2], d[1, 2], np.arctan2(d[1, 0], d[0, 0])]) / 0.25
         recs.append(render_record(world, poses[t], t, vel, scintillation=scintillation))
     return recs, poses, reflector_pixels(world, poses[0])
+
+
+# ---------------------------------------------------------------------------------------------------- long sequences
+class StreamWorld:
+    """Unbounded reflector world for long trajectories (BASELINE configs 3 / 4: the 8 866-frame, 9 km full_seq_1 path):
+    reflectors are generated per TILE x TILE metre tile from a hash of (seed, tile), so every pose sees the same ~density *
+    170^2 reflectors around it however far the path goes, and two visits of one place see the same reflectors."""
+    TILE = 50.0
+
+    def __init__(self, seed: int, per_tile: int = 40, mover_fraction: float = 0.0):
+        self.seed, self.per_tile, self.mover_fraction = seed, per_tile, mover_fraction
+        self._cache = {}
+
+    def tile(self, ix: int, iy: int):
+        key = (ix, iy)
+        if key not in self._cache:
+            rng = np.random.default_rng([self.seed & 0x7fffffff, ix & 0xffffffff, iy & 0xffffffff])
+            xy = (np.array([ix, iy]) + rng.random((self.per_tile, 2))) * self.TILE
+            amp = rng.uniform(70, 136, size=self.per_tile)
+            vel = rng.uniform(-6, 6, size=(self.per_tile, 2)) * (rng.random((self.per_tile, 1)) < self.mover_fraction)
+            if len(self._cache) > 4096:
+                self._cache.clear()
+            self._cache[key] = (xy, amp, vel)
+        return self._cache[key]
+
+    def around(self, x: float, y: float, radius_m: float = 95.0):
+        """(positions (n,2) at t = 0, amplitudes (n,), velocities (n,2) m/s) of the tiles within radius of (x, y)"""
+        i0, i1 = int(np.floor((x - radius_m) / self.TILE)), int(np.floor((x + radius_m) / self.TILE))
+        j0, j1 = int(np.floor((y - radius_m) / self.TILE)), int(np.floor((y + radius_m) / self.TILE))
+        parts = [self.tile(i, j) for i in range(i0, i1 + 1) for j in range(j0, j1 + 1)]
+        return np.vstack([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.vstack([p[2] for p in parts])
+
+
+class _LocalWorld:
+    """adapter: the reflectors around one pose in the shape render_record expects"""
+
+    def __init__(self, seed, static, amp):
+        self.seed, self.static, self.amp = seed, static, amp
+        self.movers, self.mover_vel = np.zeros((0, 2)), np.zeros((0, 2))
+
+
+def render_stream_record(world: StreamWorld, pose, t_index: int, velocity=None, scintillation: float = 0.0):
+    """one record of a StreamWorld seen from `pose` at frame t_index (movers advance 0.25 s per frame)"""
+    xy, amp, vel = world.around(pose[0], pose[1])
+    return render_record(_LocalWorld(world.seed, xy + vel * (0.25 * t_index), amp), pose, t_index, velocity, scintillation=scintillation)
+
+
+def poses_from_deltas(deltas, pose0=(0.0, 0.0, 0.0)):
+    """ground-truth style body-frame motions (n, 3) [dx, dy, dth] -> (n + 1, 3) poses, pose0 first"""
+    T = se2(*pose0)
+    out = [np.array(pose0, float)]
+    for dx, dy, dth in np.asarray(deltas, float):
+        T = T @ se2(dx, dy, dth)
+        out.append(np.array([T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])]))
+    return np.array(out)
+
+
+def _render_job(job):
+    seed, per_tile, mover_fraction, pose, t, vel, scint = job
+    return render_stream_record(StreamWorld(seed, per_tile, mover_fraction), pose, t, vel, scint)
+
+
+def stream_jobs(world: StreamWorld, poses, distortion: bool = False, scintillation: float = 0.0):
+    """picklable render jobs for frames 0..len(poses)-1 (use with multiprocessing.Pool.imap(_render_job, jobs))"""
+    jobs = []
+    for t, pose in enumerate(poses):
+        vel = None
+        if distortion and t > 0:
+            d = np.linalg.inv(se2(*poses[t - 1])) @ se2(*pose)
+            vel = np.array([d[0, 2], d[1, 2], np.arctan2(d[1, 0], d[0, 0])]) / 0.25
+        jobs.append((world.seed, world.per_tile, world.mover_fraction, np.asarray(pose, float), t, vel, scintillation))
+    return jobs
