@@ -193,7 +193,8 @@ int32_t roam_engine_destroy(roam_ctx *ctx);
 /* copy one raw record (rows x stride u8) into pool slot idx */
 int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *rec);
 /* raw-record ingest (reference parseData.py:160-226 loads one PNG per frame; here n records of rows x stride u8,
- * `host_stride` bytes apart in PINNED host memory, are copied to pool slots pool_idx0.. on a copy stream that
+ * `host_stride` bytes apart in PINNED host memory, are copied to pool slots pool_idx0.. (only the payload_off + clip
+ * bytes of every row that the path reads cross PCIe) on a copy stream that
  * overlaps the compute stream).  roam_engine_step waits for every upload enqueued before it;
  * roam_engine_fence makes later uploads wait for the steps enqueued so far (double-buffered pools). */
 int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t n, const uint8_t *host_records, int64_t host_stride);

@@ -84,15 +84,15 @@ struct Engine {
     bool rt_on = false;
     int rt_mode = 1;                                // 0 = suspended, 1 = lanes that ran out of features, 2 = every lane (measurement)
     uint8_t *kfb = nullptr;                         // 8e: packed keyframe payload (RCCL broadcast buffer)
-    hipEvent_t ev[ST_COUNT + 1];
-    hipEvent_t ev_join, ev_pk0, ev_pk1;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
-    hipEvent_t ev_klt[4], ev_g4[4];                // back-end milestones stage A of step N+3 waits for
-    hipEvent_t ev_warp;                            // end of stage A (stage B waits for it)
-    hipEvent_t ev_idx, ev_peaks;                   // scan indices uploaded / peak kernel done
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    hipEvent_t ev_join = nullptr, ev_pk0 = nullptr, ev_pk1 = nullptr;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
+    hipEvent_t ev_klt[4] = {}, ev_g4[4] = {};                // back-end milestones stage A of step N+3 waits for
+    hipEvent_t ev_warp = nullptr;                            // end of stage A (stage B waits for it)
+    hipEvent_t ev_idx = nullptr, ev_peaks = nullptr;                   // scan indices uploaded / peak kernel done
     // per-step boundaries of the three front-end kernels (before peaks | peaks/warp | warp/pyramid | after pyramid),
     // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
     // region without synchronising inside it (roam_engine_kernel_avg)
-    hipEvent_t tr_ev[64][6];
+    hipEvent_t tr_ev[64][6] = {};
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
@@ -421,13 +421,16 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (void *p : e->allocs) hipFree(p);
-    if (e->ev_ok) { for (auto &ev : e->ev) hipEventDestroy(ev); hipEventDestroy(e->ev_join); hipEventDestroy(e->ev_pk0); hipEventDestroy(e->ev_pk1);
-                    for (int i = 0; i < 4; i++) { hipEventDestroy(e->ev_klt[i]); hipEventDestroy(e->ev_g4[i]); } hipEventDestroy(e->ev_warp); hipEventDestroy(e->ev_idx); hipEventDestroy(e->ev_peaks); }
+    // every event handle starts out null, so a creation that failed half way leaks nothing
+    auto kill = [](hipEvent_t &ev) { if (ev) { hipEventDestroy(ev); ev = nullptr; } };
+    for (auto &ev : e->ev) kill(ev);
+    kill(e->ev_join); kill(e->ev_pk0); kill(e->ev_pk1); kill(e->ev_warp); kill(e->ev_idx); kill(e->ev_peaks);
+    for (int i = 0; i < 4; i++) { kill(e->ev_klt[i]); kill(e->ev_g4[i]); }
+    for (auto &row : e->tr_ev) for (auto &ev : row) kill(ev);
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->results_host) hipHostFree(e->results_host);
     for (auto &ev : e->ev_res) if (ev) hipEventDestroy(ev);
     if (e->ev_pool) hipEventDestroy(e->ev_pool);
-    if (e->tr_ok) for (auto &row : e->tr_ev) for (auto &ev : row) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
     delete e;
@@ -589,9 +592,13 @@ int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t
 {
     ENGINE();
     ARG_CHECK(ctx, host_records && n >= 1 && pool_idx0 >= 0 && pool_idx0 + n <= e->cfg.pool_scans && (host_stride == 0 || host_stride >= (int64_t)e->rec_bytes));
+    // only the bytes the path reads cross PCIe: metadata + the clipped payload of every row (2 036 of 3 779 bytes for the
+    // Oxford record at the 87.5 m clip) - a strided 2-D copy per record; the rest of the pool row is never touched
+    const size_t width = (size_t)e->cfg.payload_off + (size_t)e->cfg.clip;
     for (int i = 0; i < n; i++)
-        HIP_TRY(ctx, hipMemcpyAsync(e->pool + (size_t)(pool_idx0 + i) * e->rec_bytes, host_records + (size_t)i * host_stride, e->rec_bytes,
-                                    hipMemcpyHostToDevice, ctx->stream3));
+        HIP_TRY(ctx, hipMemcpy2DAsync(e->pool + (size_t)(pool_idx0 + i) * e->rec_bytes, (size_t)e->cfg.stride,
+                                      host_records + (size_t)i * host_stride, (size_t)e->cfg.stride, width, (size_t)e->cfg.rows,
+                                      hipMemcpyHostToDevice, ctx->stream3));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_up, ctx->stream3));
     e->uploads_pending = true;
     return ROAM_OK;

@@ -147,11 +147,17 @@ def main():
     a0 = src_txt.index("srcCoord = np.array(")
     a1 = src_txt.index("targetCoord = np.array(")
     a2 = src_txt.index("dx,dy,dth")
-    ns = {"np": np}
-    exec(src_txt[a0:a1], ns)
-    exec(src_txt[a1:a2], ns)
-    real_src = np.asarray(ns["srcCoord"], dtype=np.float64)
-    real_tgt = np.asarray(ns["targetCoord"], dtype=np.float64)
+    # the reference is untrusted public content: nothing of it is executed - the bracketed number lists are cut out and
+    # parsed as literals
+    import ast
+
+    def literal_after(txt):
+        lo = txt.index("(") + 1
+        hi = txt.rindex(")")
+        return np.asarray(ast.literal_eval(txt[lo:hi].strip().rstrip(",")), dtype=np.float64)
+
+    real_src = literal_after(src_txt[a0:a1])
+    real_tgt = literal_after(src_txt[a1:a2])
     assert real_src.shape == (95, 2) and real_tgt.shape == (95, 2)
     cases = {"real95_f64": (real_src, real_tgt),
              "real95_f32": (real_src.astype(np.float32), real_tgt.astype(np.float32))}
