@@ -192,18 +192,18 @@ def run_rank(args):
             eng = Engine(B, 2 * B, ctx=ctx, motion_distortion=not args.no_md, retrack_on_device=not args.no_retrack, retrack_slots=args.retrack_slots)
             engs = [eng]
             per = B // Dn_
-            pinned = ctx.host_alloc((Dn_ * T, 400, 3779))
-            for d in range(Dn_):
-                for t in range(T):
-                    pinned[d * T + t] = seqs[d][0][t]
-
+            # every lane's record has its own pinned source (T x B records, 1.5 MB each): the copy kernel reads host memory
+            # through the GPU's caches, so a replicated source would be served from cache instead of crossing PCIe
+            pinned = ctx.host_alloc((T, B, 400, 3779))
+            for t in range(T):
+                for d in range(Dn_):
+                    lo, hi = d * per, (B if d == Dn_ - 1 else (d + 1) * per)
+                    pinned[t, lo:hi] = seqs[d][0][t]
             cyc = cyc_full[1:] + cyc_full[:1]
 
             def upload(step, half):
                 t = 0 if step < 0 else cyc[step % len(cyc)]
-                for d in range(Dn_):
-                    n = per if d < Dn_ - 1 else B - per * (Dn_ - 1)
-                    eng.upload_scans_async(half * B + d * per, pinned[d * T + t], n=n, stride=0)
+                eng.upload_scans_async(half * B, pinned[t], n=B)
 
             upload(-1, 0)
             eng.synchronize()

@@ -410,6 +410,22 @@ __global__ __launch_bounds__(256) void kf_pack_kernel(uint8_t *__restrict__ buf,
     for (int j = t; j < 2 * P; j += nt) pk[j] = ps[j];
 }
 
+// f2 ingest: record i, rows 4 per workgroup (one wavefront per row): bytes [0, width) of every row from pinned host memory
+// into the pool.  Source rows start at arbitrary alignment (stride 3779), so a lane loads 16 bytes at byte granularity
+// through a packed unaligned vector type and stores them unaligned as well; the tail is copied byte-wise.
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+__global__ __launch_bounds__(256) void ingest_rows_kernel(const uint8_t *__restrict__ host, int64_t host_stride, uint8_t *__restrict__ pool,
+                                                          int64_t rec_bytes, int rows, int stride, int width)
+{
+    const int rec = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const uint8_t *s = host + (int64_t)rec * host_stride + (int64_t)row * stride;
+    uint8_t *d = pool + (int64_t)rec * rec_bytes + (int64_t)row * stride;
+    const int nvec = width / 16;
+    for (int v = lane; v < nvec; v += 64) *reinterpret_cast<u32x4_a1 *>(d + 16 * v) = *reinterpret_cast<const u32x4_a1 *>(s + 16 * v);
+    for (int b = nvec * 16 + lane; b < width; b += 64) d[b] = s[b];
+}
+
 // ------------------------------------------------------------------------------ API
 extern "C" {
 
@@ -593,12 +609,12 @@ int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t
     ENGINE();
     ARG_CHECK(ctx, host_records && n >= 1 && pool_idx0 >= 0 && pool_idx0 + n <= e->cfg.pool_scans && (host_stride == 0 || host_stride >= (int64_t)e->rec_bytes));
     // only the bytes the path reads cross PCIe: metadata + the clipped payload of every row (2 036 of 3 779 bytes for the
-    // Oxford record at the 87.5 m clip) - a strided 2-D copy per record; the rest of the pool row is never touched
-    const size_t width = (size_t)e->cfg.payload_off + (size_t)e->cfg.clip;
-    for (int i = 0; i < n; i++)
-        HIP_TRY(ctx, hipMemcpy2DAsync(e->pool + (size_t)(pool_idx0 + i) * e->rec_bytes, (size_t)e->cfg.stride,
-                                      host_records + (size_t)i * host_stride, (size_t)e->cfg.stride, width, (size_t)e->cfg.rows,
-                                      hipMemcpyHostToDevice, ctx->stream3));
+    // Oxford record at the 87.5 m clip).  A copy KERNEL on the copy stream reads the pinned host memory directly (it is
+    // device-visible) with 16-byte loads - hipMemcpy2DAsync moves such rows one by one (270 scan pairs/s measured)
+    const int width = e->cfg.payload_off + e->cfg.clip;
+    hipLaunchKernelGGL(ingest_rows_kernel, dim3((e->cfg.rows + 3) / 4, n), dim3(256), 0, ctx->stream3, host_records, host_stride,
+                       e->pool + (size_t)pool_idx0 * e->rec_bytes, (int64_t)e->rec_bytes, e->cfg.rows, e->cfg.stride, width);
+    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_up, ctx->stream3));
     e->uploads_pending = true;
     return ROAM_OK;
