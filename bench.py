@@ -375,7 +375,9 @@ def roofline(eng, args, B, retrack_fraction):
     for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            if tj.get("lanes") == B and kname in tj["kernels"]:
+            # (the detection kernels process `slots` detections per launch whatever the lane count: a pass with lanes == slots
+            #  measures the very same launches)
+            if (tj.get("lanes") == B or (dom.startswith("doh") and tj.get("lanes") == slots)) and kname in tj["kernels"]:
                 k = tj["kernels"][kname]
                 traffic = k.get("traffic_bytes_per_launch")
                 if k.get("valu_wave_insts_per_launch"):
@@ -387,7 +389,10 @@ def roofline(eng, args, B, retrack_fraction):
             continue
     iso_frac = algo_bytes / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
     bound = "valu_issue" if (valu_frac is not None and valu_frac > iso_frac) else "hbm"
-    return {"bound": bound, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    detail = {"doh_det_maxima": "74 float64 L1 reads per pixel: texture addresser (TA_BUSY) 98 % busy, VALU issue 32 %, HBM 3 % (profiles/r02_pmc_det_kernel.txt)",
+              "doh_integral": "two sequential-order float64 prefix passes: 99 MB of HBM traffic per detection",
+              "warp_quantise": "VALU / LDS issue (round-1 PMC)"}.get(dom)
+    return {"bound": bound, "bound_detail": detail, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
             "valu_issue_frac_isolated": None if valu_frac is None else round(valu_frac, 4),
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,

@@ -9,10 +9,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench
 cp $O/prof/*/*kernel_stats.csv $O/kernel_stats.csv
 python3 profiles/trace_summary.py $O/prof > $O/trace_summary.csv 2>/dev/null
 OUT=$O/pmc; mkdir -p $OUT
-ARGS="bench.py --steps 4 --warmup 2 --cpu-pairs 0 --kernel-reps 3"
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ARGS > $OUT/$name.log 2>&1; }
+# PMC serialises every dispatch: at 4096 lanes the 70 000 dispatches of the lane set-up alone take longer than a GPU slot lasts (rocprofv3 aborted);
+# the detection kernels work on `retrack_slots` = 512 detections per launch whatever the lane count, so 512 lanes measure the same launches
+ARGS="bench.py --lanes 512 --retrack-slots 512 --steps 4 --warmup 2 --cpu-pairs 0 --kernel-reps 3"
+run() { name=$1; shift; timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ARGS > $OUT/$name.log 2>&1; }
 run A SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD
 run C FETCH_SIZE
 run D WRITE_SIZE
-python3 profiles/pmc_traffic.py $OUT 4096 $O/pmc_traffic.json
+python3 profiles/pmc_traffic.py $OUT 512 $O/pmc_traffic.json
 cut -c1-300 $O/bench_unprofiled.json; head -14 $O/kernel_stats.csv | cut -d, -f1-5
