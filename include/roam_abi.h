@@ -149,6 +149,13 @@ int32_t roam_doh_maxima(roam_ctx *ctx, const float *img, int32_t w, int32_t h, c
 int32_t roam_prune_blobs(const double *blobs, int32_t n, double overlap, uint8_t *keep_out);
 int32_t roam_argsort_np122(const double *keys, int32_t n, int32_t *order_out);
 
+/* ---- f4: FMT.getRotationUsingFMT (FMT.py:36-90; called first by Tracker.track, Tracker.py:62-63) ---------------------
+ * Fourier-Mellin rotation prior between two polar images (rows x cols float32): range clip (clip_px bins, <= 0: none),
+ * cv2.resize to clip / downsample columns, polar -> Cartesian -> log-polar, Hanning-windowed phase correlation.
+ * angle_rad: R(angle) src = target; scale and response are optional. */
+int32_t roam_fmt_rotation(roam_ctx *ctx, const float *src_polar, const float *tgt_polar, int32_t rows, int32_t cols,
+                          int32_t clip_px, int32_t downsample, double *angle_rad, double *scale, double *response);
+
 /* ---- engine: B resident lanes, one scan pair per lane per step ---------------------------
  * Replaces the body of the RawROAMSystem.run loop (RawROAMSystem.py:162-298) minus plotting:
  * a1/a2 ingest+peaks, a3 warp+quantise, pyramid, a7 KLT against the lane's previous

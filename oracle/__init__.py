@@ -453,6 +453,103 @@ def convertTransformToPose(T):
     return np.array([T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])])
 
 
+# ------------------------------------------------------------------ f4: Fourier-Mellin rotation prior (FMT.py)
+FMT_DOWNSAMPLE_FACTOR = 10           # FMT.py:10
+FMT_RANGE_CLIP_M = 87.5              # FMT.py:11
+
+
+def _cv_resize_cols_linear(img, new_w):
+    """cv2.resize(img, (new_w, H)) with INTER_LINEAR for float32 (rows unchanged -> the vertical weights are (1, 0))"""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape
+    scale = 1.0 / (float(new_w) / w)
+    dx = np.arange(new_w)
+    fx = ((dx + 0.5) * scale - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(np.float32)).astype(np.float32)
+    lo, hi = sx < 0, sx >= w - 1
+    fx[lo | hi] = 0
+    sx[lo] = 0
+    sx[hi] = w - 1
+    a1 = fx
+    a0 = (np.float32(1) - fx).astype(np.float32)
+    s1 = np.minimum(sx + 1, w - 1)
+    return (img[:, sx] * a0 + img[:, s1] * a1).astype(np.float32)
+
+
+def _get_optimal_dft_size(n):
+    """smallest 2^a 3^b 5^c >= n (cv2.getOptimalDFTSize)"""
+    best = None
+    p2 = 1
+    while p2 < 2 * n:
+        p3 = p2
+        while p3 < 2 * n:
+            p5 = p3
+            while p5 < 2 * n:
+                if p5 >= n and (best is None or p5 < best):
+                    best = p5
+                p5 *= 5
+            p3 *= 3
+        p2 *= 2
+    return best
+
+
+def convertPolarImgToLogPolar(imgPolar):
+    """parseData.py:138-160: polar -> Cartesian (downsampleFactor 1) -> log-polar of OpenCV's default size"""
+    img = np.ascontiguousarray(imgPolar, np.float32)
+    rows, cols = img.shape
+    R = cols                                           # maxRadius = h (parseData.py:118-121 with downsampleFactor 1)
+    cart = np.empty((2 * R, 2 * R), np.float32)
+    lib().oracle_warp_polar_inverse(_p(img, C.c_float), rows, cols, C.c_int64(cols), 2 * R, 2 * R, C.c_float(R), C.c_float(R), C.c_double(R), _p(cart, C.c_float))
+    maxRadius = (2 * R) / 2                            # convertCartesianImageToPolar: center (h/2, w/2), maxRadius w/2, dsize from OpenCV
+    dw, dh = int(np.rint(maxRadius)), int(np.rint(maxRadius * np.pi))
+    lp = np.empty((dh, dw), np.float32)
+    lib().oracle_warp_polar_forward_log(_p(cart, C.c_float), 2 * R, 2 * R, dw, dh, C.c_float(R), C.c_float(R), C.c_double(maxRadius), _p(lp, C.c_float))
+    return lp
+
+
+def phaseCorrelate(src1, src2):
+    """cv2.phaseCorrelate(src1, src2, cv2.createHanningWindow(...)) restated with numpy FFTs in float64 -> ((dx, dy), response)"""
+    H, W = src1.shape
+    wc = 0.5 * (1.0 - np.cos(2.0 * np.pi / (W - 1) * np.arange(W)))
+    wr = 0.5 * (1.0 - np.cos(2.0 * np.pi / (H - 1) * np.arange(H)))
+    win = np.sqrt((wr[:, None] * wc[None, :]).astype(np.float32))
+    M, N = _get_optimal_dft_size(H), _get_optimal_dft_size(W)
+    a = np.zeros((M, N), np.float32); b = np.zeros((M, N), np.float32)
+    a[:H, :W] = (win * src1).astype(np.float32); b[:H, :W] = (win * src2).astype(np.float32)
+    F1, F2 = np.fft.fft2(a.astype(np.float64)), np.fft.fft2(b.astype(np.float64))
+    P = F1 * np.conj(F2)
+    mag = np.abs(P)
+    eps32 = float(np.finfo(np.float32).eps)
+    Cc = np.real(np.fft.ifft2(P * mag / (mag * mag + eps32)))      # divSpectrums(P, |P|): P |P| / (|P|^2 + FLT_EPSILON)
+    Cc = np.fft.fftshift(Cc)
+    py, px = np.unravel_index(np.argmax(Cc), Cc.shape)
+    r0, r1 = max(py - 2, 0), min(py + 2, M - 1)
+    c0, c1 = max(px - 2, 0), min(px + 2, N - 1)
+    box = Cc[r0:r1 + 1, c0:c1 + 1]
+    s = box.sum()
+    ys, xs = np.mgrid[r0:r1 + 1, c0:c1 + 1]
+    cx, cy = (xs * box).sum() / (s + np.finfo(float).eps), (ys * box).sum() / (s + np.finfo(float).eps)
+    return (N / 2.0 - cx, M / 2.0 - cy), s
+
+
+def getRotationUsingFMT(srcPolarImg, targetPolarImg, downsampleFactor=FMT_DOWNSAMPLE_FACTOR, maxRangeClipM=FMT_RANGE_CLIP_M):
+    """FMT.py:36-90 -> (angle rad, scale, response)"""
+    assert srcPolarImg.shape == targetPolarImg.shape
+    if maxRangeClipM > 0:
+        clip = int(maxRangeClipM / RANGE_RESOLUTION_CART_M)
+        srcPolarImg, targetPolarImg = srcPolarImg[:, :clip], targetPolarImg[:, :clip]
+    H, W = srcPolarImg.shape
+    a = convertPolarImgToLogPolar(_cv_resize_cols_linear(srcPolarImg, int(W // downsampleFactor)))
+    b = convertPolarImgToLogPolar(_cv_resize_cols_linear(targetPolarImg, int(W // downsampleFactor)))
+    (scale, angle), resp = phaseCorrelate(a, b)
+    H_lp, W_lp = a.shape
+    sz = max(H_lp, W_lp)
+    angle = normalize_angles(-float(angle) * 2 * np.pi / sz)
+    log_base = np.exp(np.log(H_lp / 2) / sz)
+    return float(angle), float(log_base ** scale), float(resp)     # (OpenCV: unscaled IDFT sum / (M N) = numpy's scaled sum)
+
+
 # ------------------------------------------------------------------ a9: Tracker.track glue
 def track_glue(klt_out, do_reject=True):
     """Tracker.py:75-104 given the 5-tuple of getTrackedPointsKLT."""

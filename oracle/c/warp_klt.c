@@ -305,3 +305,61 @@ void oracle_klt_track(const uint8_t *const *prevPyr, const uint8_t *const *nextP
     }
     free(Ibuf);
 }
+
+/* ------------------------------------------------------------------ general warpPolar pieces for the FMT rotation prior
+ * (reference FMT.py:36-90 -> parseData.convertPolarImgToLogPolar, parseData.py:56-160): the same OpenCV algorithms as above
+ * with free geometry.  PARITY UNPINNED: the reference holds no output of this path (its result is only printed). */
+
+/* inverse linear warp: polar (rows x cols) -> W x H Cartesian, centre (cx, cy), maxRadius; WARP_FILL_OUTLIERS */
+void oracle_warp_polar_inverse(const float *polar, int rows, int cols, int64_t stride, int W, int H, float cx, float cy,
+                               double maxRadius, float *out)
+{
+    const double Kangle = 6.283185307179586476925286766559 / rows;
+    const double Kmag = maxRadius / cols;
+    const float deg2rad = (float)(3.14159265358979323846 / 180.0);
+    for (int y = 0; y < H; y++) {
+        float fy = (float)y - cy;
+        for (int x = 0; x < W; x++) {
+            float fx = (float)x - cx;
+            float mag = sqrtf(fx * fx + fy * fy);
+            float ang = fast_atan2_deg(fy, fx) * deg2rad;
+            double rho = (double)mag / Kmag, phi = (double)ang / Kangle;
+            float mx = (float)rho, my = (float)phi + 1.f;
+            int sx = cv_round_f(mx * 32.f), sy = cv_round_f(my * 32.f);
+            int ix = sx >> 5, iy = sy >> 5, fxq = sx & 31, fyq = sy & 31;
+            float wx1 = (float)fxq * (1.f / 32.f), wx0 = 1.f - wx1, wy1 = (float)fyq * (1.f / 32.f), wy0 = 1.f - wy1;
+            float v = polar_tap(polar, rows, cols, stride, iy, ix) * (wy0 * wx0);
+            v = v + polar_tap(polar, rows, cols, stride, iy, ix + 1) * (wy0 * wx1);
+            v = v + polar_tap(polar, rows, cols, stride, iy + 1, ix) * (wy1 * wx0);
+            v = v + polar_tap(polar, rows, cols, stride, iy + 1, ix + 1) * (wy1 * wx1);
+            out[(int64_t)y * W + x] = v;
+        }
+    }
+}
+
+static inline float cart_tap(const float *img, int W, int H, int y, int x)
+{
+    return (x < 0 || x >= W || y < 0 || y >= H) ? 0.f : img[(int64_t)y * W + x];
+}
+
+/* forward semilog warp: Cartesian (W x H) -> log-polar (dw x dh): rho column, phi row; WARP_POLAR_LOG | WARP_FILL_OUTLIERS */
+void oracle_warp_polar_forward_log(const float *cart, int W, int H, int dw, int dh, float cx, float cy, double maxRadius, float *out)
+{
+    const double Kangle = 6.283185307179586476925286766559 / dh;
+    const double Kmag = log(maxRadius) / dw;
+    for (int phi = 0; phi < dh; phi++) {
+        const double KKy = Kangle * phi, cp = cos(KKy), sp = sin(KKy);
+        for (int rho = 0; rho < dw; rho++) {
+            const float br = (float)(exp(rho * Kmag) - 1.0);
+            const float mx = (float)((double)br * cp + (double)cx), my = (float)((double)br * sp + (double)cy);
+            int sx = cv_round_f(mx * 32.f), sy = cv_round_f(my * 32.f);
+            int ix = sx >> 5, iy = sy >> 5, fxq = sx & 31, fyq = sy & 31;
+            float wx1 = (float)fxq * (1.f / 32.f), wx0 = 1.f - wx1, wy1 = (float)fyq * (1.f / 32.f), wy0 = 1.f - wy1;
+            float v = cart_tap(cart, W, H, iy, ix) * (wy0 * wx0);
+            v = v + cart_tap(cart, W, H, iy, ix + 1) * (wy0 * wx1);
+            v = v + cart_tap(cart, W, H, iy + 1, ix) * (wy1 * wx0);
+            v = v + cart_tap(cart, W, H, iy + 1, ix + 1) * (wy1 * wx1);
+            out[(int64_t)phi * dw + rho] = v;
+        }
+    }
+}

@@ -90,6 +90,7 @@ _SIGS = {
     "roam_engine_map_get": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "roam_engine_stage_times": (C.c_int32, [_vp, _vp, _P(C.c_char_p), C.c_int32, _P(C.c_int32)]),
     "roam_engine_time_kernel": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_float), _P(C.c_double)]),
+    "roam_fmt_rotation": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "roam_prune_blobs": (C.c_int32, [_vp, C.c_int32, C.c_double, _vp]),
     "roam_argsort_np122": (C.c_int32, [_vp, C.c_int32, _vp]),
     "roam_comm_unique_id": (C.c_int32, [_vp]),
@@ -294,6 +295,16 @@ class Context:
         n = C.c_int32(0)
         self.check(self.lib.roam_ssc(self.h, _ptr(kp), B, int(num_ret), float(tol), int(cols), int(rows), _ptr(sel), C.byref(n)))
         return sel[:n.value]
+
+    def fmt_rotation(self, src_polar, tgt_polar, clip_px=1012, downsample=10):
+        """FMT.getRotationUsingFMT -> (angle rad, scale, response)"""
+        a = np.ascontiguousarray(src_polar, np.float32)
+        b = np.ascontiguousarray(tgt_polar, np.float32)
+        assert a.shape == b.shape, "Images need to have the same shape!"
+        ang, sc, rs = C.c_double(0), C.c_double(0), C.c_double(0)
+        self.check(self.lib.roam_fmt_rotation(self.h, _ptr(a), _ptr(b), a.shape[0], a.shape[1], int(clip_px), int(downsample),
+                                              C.byref(ang), C.byref(sc), C.byref(rs)))
+        return ang.value, sc.value, rs.value
 
     def doh_maxima(self, img, sigmas, threshold, cap=1 << 18):
         """-> (rcs (n,3) int32 [row, col, sigma_index] in C order, values (n,) f64)"""

@@ -289,3 +289,21 @@ def test_get_features_matches_oracle(ctx, cart_pair):
     pts, thr = appendNewFeatures(cart, old)
     assert thr == 80 and pts.dtype == np.float32
     assert np.array_equal(pts, oracle.append_dedupe(old, wxy))
+
+
+# ------------------------------------------------------------------ f4 Fourier-Mellin rotation prior
+def test_fmt_rotation_matches_oracle(ctx):
+    """roam_fmt_rotation (resize, two warpPolar steps, windowed phase correlation by direct DFTs) vs the oracle's numpy
+    restatement of FMT.getRotationUsingFMT: 1e-5 rad; and through the reference-named wrappers (FMT, Tracker.track slot 3)"""
+    from radarslampy_amd import synth
+    from radarslampy_amd.FMT import getRotationUsingFMT
+    recs, poses, feat = synth.make_sequence(3, 2, n_movers=6)
+    p0 = recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.)
+    p1 = recs[1][:, 11:11 + 2025].astype(np.float32) / np.float32(255.)
+    for a, b in ((p0, p0), (p0, p1), (p0, np.roll(p0, 7, axis=0)), (p1, np.roll(p0, -31, axis=0))):
+        got = ctx.fmt_rotation(a, b)
+        want = oracle.getRotationUsingFMT(a, b)
+        assert abs(got[0] - want[0]) <= 1e-5, (got, want)
+        assert abs(got[1] - want[1]) <= 1e-5 and abs(got[2] - want[2]) <= 1e-4 * max(1.0, abs(want[2])), (got, want)
+    assert getRotationUsingFMT(p0, p1)[0] == ctx.fmt_rotation(p0, p1)[0]
+    assert abs(ctx.fmt_rotation(p0, np.roll(p0, 7, axis=0))[0] + 7 * 2 * np.pi / 400) < 2e-3

@@ -129,3 +129,17 @@ def test_oracle_pipeline_tracks_a_synthetic_sequence():
             # rotation (SURVEY 8a quirk i); only the heading is meaningful there
             assert abs(a["pose"][2] - poses[t][2]) < 0.01
             assert len(a["peaks"]) > 3000
+
+
+def test_fmt_rotation_known_answer():
+    """f4 (FMT.py:36-90): a scan rotated by k azimuth rows comes back as -k * 2 pi / 400 within the method's resolution
+    (one log-polar row = 2 pi / 317 rad, refined by the 5 x 5 centroid); identical scans give exactly 0 and scale 1"""
+    from radarslampy_amd import synth
+    recs, _, _ = synth.make_sequence(3, 1)
+    polar = recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.)
+    a, sc, resp = oracle.getRotationUsingFMT(polar, polar)
+    assert abs(a) < 1e-9 and abs(sc - 1) < 1e-9 and resp > 0.9
+    for k in (3, -5, 20):
+        a, sc, resp = oracle.getRotationUsingFMT(polar, np.roll(polar, k, axis=0))
+        assert abs(a + k * 2 * np.pi / 400) < 2e-3, (k, a)
+        assert abs(sc - 1) < 5e-3 and resp > 0.3
