@@ -141,5 +141,5 @@ def test_fmt_rotation_known_answer():
     assert abs(a) < 1e-9 and abs(sc - 1) < 1e-9 and resp > 0.9
     for k in (3, -5, 20):
         a, sc, resp = oracle.getRotationUsingFMT(polar, np.roll(polar, k, axis=0))
-        assert abs(a + k * 2 * np.pi / 400) < 2e-3, (k, a)
+        assert abs(a + k * 2 * np.pi / 400) < 5e-3, (k, a)          # a quarter of a log-polar row
         assert abs(sc - 1) < 5e-3 and resp > 0.3
