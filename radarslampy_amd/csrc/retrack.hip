@@ -146,9 +146,18 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #define RT_BR (RT_TH + 2 + 14 + 16)        // 48 rows: offsets -14 .. +16 around the 18 determinant rows
 #define RT_BC (RT_TW + 2 + 14 + 16)        // 96 columns
 #define RT_DET_THREADS 256
+// persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
+// with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
+#define RT_DET_GRID 4093
+#ifndef RT_DET_LDS
+#define RT_DET_LDS 1
+#endif
 __global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
 {
     __shared__ double det[2][RT_TH + 2][RT_TW + 2];
+#if RT_DET_LDS
+    __shared__ double sblk[RT_BR * RT_BC];
+#endif
     // persistent-style grid: the number of live slots is known only on the device, and two million empty workgroups per
     // chunk cost more to dispatch than the whole tracking step
     const int nact = min(P, max(0, *a.rt_n - first));
@@ -164,8 +173,41 @@ __global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, i
     // waves per SIMD against 142 us for L1 reads at full occupancy
     const bool interior = r0 >= RT_HALO && r0 - RT_HALO + RT_BR <= H && c0 >= RT_HALO && c0 - RT_HALO + RT_BC <= W && a.size1 == 15 && a.size2 == 30;
     // outside the image the 3x3x3 footprint sees nothing that could exceed v (mode = 'constant', 0 < threshold < v)
+#if RT_DET_LDS
+    if (a.size1 == 15 && a.size2 == 30) {
+        // stage the 48 x 96 block of the integral image once (source indices clipped at the image border: a clipped corner index
+        // never leaves rows r0-15 .. r0+32 / columns c0-15 .. c0+80); then every thread walks its positions with the corner loads
+        // of the NEXT determinant in flight while the arithmetic of the current one runs (layer 15, layer 30, layer 15, ...)
+        for (int i = t; i < RT_BR * RT_BC; i += RT_DET_THREADS) {
+            const int rr = i / RT_BC, cc = i - rr * RT_BC;
+            sblk[i] = interior ? S[(int64_t)(r0 - RT_HALO + rr) * W + (c0 - RT_HALO + cc)]
+                               : S[(int64_t)clipi(r0 - RT_HALO + rr, 0, H - 1) * W + clipi(c0 - RT_HALO + cc, 0, W - 1)];
+        }
+        __syncthreads();
+        constexpr int NPOS = (RT_TH + 2) * (RT_TW + 2);
+        auto sweep = [&](const auto &acc) {
+            int rr = t / (RT_TW + 2), cc = t - rr * (RT_TW + 2);
+            double va[32], vb[32];
+            if (t < NPOS) hessian_corners<15>(acc, r0 + rr - 1, c0 + cc - 1, va);
+            for (int i = t; i < NPOS; i += RT_DET_THREADS) {
+                const int r = r0 + rr - 1, c = c0 + cc - 1;
+                hessian_corners<30>(acc, r, c, vb);
+                double d0 = hessian_from_corners<15>(va);
+                int nr = rr + RT_DET_THREADS / (RT_TW + 2), nc = cc + RT_DET_THREADS % (RT_TW + 2);
+                if (nc >= RT_TW + 2) { nc -= RT_TW + 2; nr++; }
+                if (i + RT_DET_THREADS < NPOS) hessian_corners<15>(acc, r0 + nr - 1, c0 + nc - 1, va);
+                double d1 = hessian_from_corners<30>(vb);
+                if (r < 0 || r >= H || c < 0 || c >= W) { d0 = 0.0; d1 = 0.0; }     // outside the image: nothing that could exceed a maximum
+                det[0][rr][cc] = d0; det[1][rr][cc] = d1;
+                rr = nr; cc = nc;
+            }
+        };
+        if (interior) sweep(DohLdsAcc<RT_BC>{sblk, r0 - RT_HALO, c0 - RT_HALO});
+        else sweep(DohLdsClipAcc<RT_BC>{sblk, r0 - RT_HALO, c0 - RT_HALO, H, W});
+    } else
+#endif
     {
-        // 2 x 18 x 66 = 2376 (layer, row, column) items over the workgroup: 9.3 per thread
+        // general box sizes (not used by the engine's fixed parameters): 2 x 18 x 66 = 2376 (layer, row, column) items
         constexpr int NPOS = (RT_TH + 2) * (RT_TW + 2);
         int l = t / NPOS, rem = t - l * NPOS;
         int rr = rem / (RT_TW + 2), cc = rem - rr * (RT_TW + 2);
@@ -173,10 +215,13 @@ __global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, i
             const int r = r0 + rr - 1, c = c0 + cc - 1;
             double v = 0.0;
             if (r >= 0 && r < H && c >= 0 && c < W) {
-                // interior tiles: compile-time box sizes (15, 30) and no index clipping - the box weights 1/size^2 (two float64
-                // divisions in the general form) and every corner offset fold into constants
-                if (interior) { const DohGlobalInteriorAcc ga = {S, W}; v = l == 0 ? hessian_det_fixed<15>(ga, r, c) : hessian_det_fixed<30>(ga, r, c); }
-                else v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
+#if !RT_DET_LDS
+                if (a.size1 == 15 && a.size2 == 30) {
+                    if (interior) { const DohGlobalInteriorAcc ga = {S, W}; v = l == 0 ? hessian_det_fixed<15>(ga, r, c) : hessian_det_fixed<30>(ga, r, c); }
+                    else { const DohGlobalAcc gc = {S, H, W}; v = l == 0 ? hessian_det_fixed<15>(gc, r, c) : hessian_det_fixed<30>(gc, r, c); }
+                } else
+#endif
+                v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
             }
             det[l][rr][cc] = v;
             rr += RT_DET_THREADS / (RT_TW + 2); cc += RT_DET_THREADS % (RT_TW + 2);
@@ -473,7 +518,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
         {
             const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
             const int64_t all = (int64_t)tx * ty * P;
-            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
+            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
         }
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
@@ -505,7 +550,7 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
         if (e != hipSuccess) return e;
         const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
         const int64_t all = (int64_t)tx * ty * P;
-        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, 256 * 16)), dim3(RT_DET_THREADS), 0, st, a, 0, P, tx, ty);
+        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, 0, P, tx, ty);
     }
     return hipGetLastError();
 }
