@@ -371,7 +371,7 @@ def roofline(eng, args, B, retrack_fraction):
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.py); null when no pass at this lane count is committed
     traffic, valu_frac, src = None, None, None
     kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_wave_kernel", "pyramid": "pyr_down_wave_kernel",
-             "doh_integral": "rt_integ_rows_kernel", "doh_det_maxima": "rt_det_mask_kernel"}[dom]
+             "doh_integral": "rt_integral_kernel", "doh_det_maxima": "rt_det_mask_kernel"}[dom]
     for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
@@ -390,7 +390,7 @@ def roofline(eng, args, B, retrack_fraction):
     iso_frac = algo_bytes / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
     bound = "valu_issue" if (valu_frac is not None and valu_frac > iso_frac) else "hbm"
     detail = {"doh_det_maxima": "74 float64 L1 reads per pixel: texture addresser (TA_BUSY) 98 % busy, VALU issue 32 %, HBM 3 % (profiles/r02_pmc_det_kernel.txt)",
-              "doh_integral": "two sequential-order float64 prefix passes: 99 MB of HBM traffic per detection",
+              "doh_integral": "one sweep, both float64 prefix sums in NumPy's sequential order: bound by the latency chain of the adds and by byte gathers from the polar record (TA), 51 MB per detection",
               "warp_quantise": "VALU / LDS issue (round-1 PMC)"}.get(dom)
     return {"bound": bound, "bound_detail": detail, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,

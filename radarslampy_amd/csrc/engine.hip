@@ -553,6 +553,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     }
     if (!ok) { roam_engine_destroy(ctx); return ROAM_E_HIP; }
     if (e->rt_on) {
+        HIP_TRY(ctx, retrack_init());
         RtArgs &r = e->rt;
         r.pool = e->pool; r.map = e->warp_map; r.feat = e->feat; r.feat_n = e->feat_n; r.vel = e->vel; r.kf_und = e->kf_und; r.res = nullptr;
     }
@@ -1122,9 +1123,9 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             }
             HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, which));
             const double npx = (double)e->W * e->W;
-            // algorithmic bytes per detection: integral image = polar payload read + float64 image written by the column pass,
-            // read and written by the row pass; determinants + maxima = float64 image read once + 1 byte per pixel written
-            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + 3.0 * npx * 8.0) : (npx * 8.0 + npx));
+            // algorithmic bytes per detection: integral image (one sweep) = polar payload + 4-byte map word per pixel read, float64
+            // image written once; determinants + maxima = float64 image read once + 1 byte per pixel written
+            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 4.0 + npx * 8.0) : (npx * 8.0 + npx));
         } else if (!strcmp(name, "pyramid")) {
             HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
             double rd = 0, wr = 0;

@@ -45,3 +45,4 @@ hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride,
                             int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
                             const int32_t *n_active, int first);
 hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which);
+hipError_t retrack_init();

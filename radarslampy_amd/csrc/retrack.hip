@@ -139,24 +139,179 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K3: determinants + maxima
-#define RT_TH 16
-#define RT_TW 64
-#define RT_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
-#define RT_BR (RT_TH + 2 + 14 + 16)        // 48 rows: offsets -14 .. +16 around the 18 determinant rows
-#define RT_BC (RT_TW + 2 + 14 + 16)        // 96 columns
-#define RT_DET_THREADS 256
+// ------------------------------------------------------------------------------------------------ K1+K2 fused: one sweep
+// One workgroup per detection walks the image in bands of RI_ROWS rows and, inside a band, in groups of RI_WAVES 64-column tiles.
+// For every (band, group) "phase" i:
+//   A(i)  column waves, lane = column: the band's RI_ROWS pixels of the column (computed from the polar record, see rt_pixel) are
+//         added one after the other to the column's running sum (a register, carried from band to band) -> tile[row][column]
+//   B(i)  the row wave, lane = row: the row's running sum walks through the group's tiles column by column (carried in a register
+//         from group to group) - the second cumsum, in place
+//   C(i)  every column wave writes its tile to the integral image
+// The tiles are double-buffered, so that between two barriers the column waves run C(i-1) and A(i+1) while the row wave runs B(i):
+// A is bound by load latency, B by the latency of 64 x RI_WAVES dependent float64 additions, and they hide each other.
+// Both cumulative sums keep NumPy's sequential order; the float64 image is written ONCE (32.8 MB per detection instead of the
+// 98.6 MB moved by the two-pass kernels above, which stay for image sizes above 2048).
+#define RI_ROWS 16
+#define RI_WAVES 4
+#define RI_GROUPS (2048 / (64 * RI_WAVES))
+#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8)
+struct __attribute__((packed)) RtU16 { uint16_t v; };                      // two neighbouring codes in one (unaligned) load
+__device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict__ p, int rows, int cols, int stride, const float *lut)
+{
+    const int ix = m & 4095, iy = (m >> 12) & 1023;
+    if (ix >= cols) return 0.f;
+    const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+    const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+    int r0 = iy - 1, r1 = iy;
+    if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
+    if (r1 >= rows) r1 -= rows;
+    const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
+    const bool i1 = ix + 1 < cols;
+    // in the last column the pair is read one byte to the left and shifted, so that no load leaves the row
+    const int back = i1 ? 0 : 1, sh = back * 8;
+    const uint32_t w0 = reinterpret_cast<const RtU16 *>(q0 - back)->v >> sh, w1 = reinterpret_cast<const RtU16 *>(q1 - back)->v >> sh;
+    const float s00 = lut[w0 & 255], s01 = i1 ? lut[w0 >> 8] : 0.f;        // lut[k] = rt_code_to_f32(k)
+    const float s10 = lut[w1 & 255], s11 = i1 ? lut[w1 >> 8] : 0.f;
+    float v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
+    v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
+    v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
+    v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
+    return v;
+}
+
+__global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs a, int first)
+{
+    extern __shared__ double ri_lds[];
+    const int ls = blockIdx.x, slot = first + ls;
+    if (slot >= *a.rt_n) return;
+    typedef double Tile[RI_ROWS][65];
+    Tile *tiles = reinterpret_cast<Tile *>(ri_lds);                        // [2][RI_WAVES]
+    const int W = a.W, H = a.W, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int nbands = (H + RI_ROWS - 1) / RI_ROWS;
+    __shared__ float lut[256];
+    if (t < 256) lut[t] = rt_code_to_f32(t);
+    __syncthreads();
+    if (wave < RI_WAVES) {
+        // ------------------------------------------------------------------------------------ column waves: C(i-1), A(i+1)
+        const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
+        double *S = a.S + (int64_t)ls * W * W;
+        const int rows = a.rows, cols = a.cols, stride = a.stride;
+        double acc[RI_GROUPS];                                             // the running sums of this thread's columns
+#pragma unroll
+        for (int g = 0; g < RI_GROUPS; g++) acc[g] = 0.0;
+        uint32_t m[RI_ROWS];                                               // the map words of the NEXT A, in flight
+        auto fetch = [&](int band, int g) {
+            const int c = min(g * 64 * RI_WAVES + 64 * wave + lane, W - 1);
+#pragma unroll
+            for (int k = 0; k < RI_ROWS; k++) m[k] = a.map[(int64_t)min(band * RI_ROWS + k, H - 1) * W + c];
+        };
+        auto A = [&](int band, int g) {
+            const int c = g * 64 * RI_WAVES + 64 * wave + lane;
+            Tile &tl = tiles[((band * RI_GROUPS + g) & 1) * RI_WAVES + wave];
+            float v[RI_ROWS];
+#pragma unroll
+            for (int k = 0; k < RI_ROWS; k++) v[k] = rt_pixel(m[k], p, rows, cols, stride, lut);
+            // the next phase's map words leave now; they land while the row wave works
+            if (g + 1 < RI_GROUPS) fetch(band, g + 1); else if (band + 1 < nbands) fetch(band + 1, 0);
+            if (c < W) {
+                double s = acc[0];                                         // g is uniform: selects, not indexed registers
+#pragma unroll
+                for (int q = 1; q < RI_GROUPS; q++) s = g == q ? acc[q] : s;
+#pragma unroll
+                for (int k = 0; k < RI_ROWS; k++) {
+                    if (band * RI_ROWS + k < H) s = __dadd_rn(s, (double)v[k]);
+                    tl[k][lane] = s;
+                }
+#pragma unroll
+                for (int q = 0; q < RI_GROUPS; q++) acc[q] = g == q ? s : acc[q];
+            }
+        };
+        auto C = [&](int band, int g) {
+            const int c = g * 64 * RI_WAVES + 64 * wave + lane;
+            const Tile &tl = tiles[((band * RI_GROUPS + g) & 1) * RI_WAVES + wave];
+            if (c < W) {
+                double *q = S + (int64_t)band * RI_ROWS * W + c;
+                const int nk = min(RI_ROWS, H - band * RI_ROWS);
+                if (nk == RI_ROWS) {
+#pragma unroll
+                    for (int k = 0; k < RI_ROWS; k++) q[(int64_t)k * W] = tl[k][lane];
+                } else
+                    for (int k = 0; k < nk; k++) q[(int64_t)k * W] = tl[k][lane];
+            }
+        };
+        fetch(0, 0);
+        A(0, 0);
+        const int nphase = nbands * RI_GROUPS;
+#pragma unroll 1
+        for (int i = 0; i < nphase; i++) {
+            __syncthreads();                                               // A(i) and B(i-1) are complete
+            if (i > 0) C((i - 1) / RI_GROUPS, (i - 1) % RI_GROUPS);
+            if (i + 1 < nphase) A((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS);
+        }
+        __syncthreads();
+        C(nbands - 1, RI_GROUPS - 1);
+    } else {
+        // ------------------------------------------------------------------------------------ the row wave: B(i)
+        for (int band = 0; band < nbands; band++) {
+            double carry = 0.0;                                            // running sum of row band * RI_ROWS + lane
+            const bool live = lane < RI_ROWS && band * RI_ROWS + lane < H;
+            for (int g = 0; g < RI_GROUPS; g++) {
+                __syncthreads();
+                if (!live) continue;
+                const int C0 = g * 64 * RI_WAVES, ncols = min(64 * RI_WAVES, W - C0);
+                Tile *tg = tiles + ((band * RI_GROUPS + g) & 1) * RI_WAVES;
+                int j = 0;
+                if (ncols >= 8) {
+                    double x[8], y[8];
+                    {
+                        const double *q = &tg[0][lane][0];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) x[u] = q[u];
+                    }
+                    for (; j + 8 <= ncols; j += 8) {                       // a batch never straddles two tiles (64 = 8 x 8)
+                        double *q = &tg[j >> 6][lane][j & 63];
+                        if (j + 16 <= ncols) {                             // the next batch is read while this one is added up
+                            const double *qn = &tg[(j + 8) >> 6][lane][(j + 8) & 63];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) y[u] = qn[u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { carry = __dadd_rn(carry, x[u]); x[u] = carry; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) q[u] = x[u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) x[u] = y[u];
+                    }
+                }
+                for (; j < ncols; j++) {
+                    double *q = &tg[j >> 6][lane][j & 63];
+                    carry = __dadd_rn(carry, *q);
+                    *q = carry;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3 (general box sizes): determinants + maxima
+#define RTG_TH 16
+#define RTG_TW 64
+#define RTG_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
+#define RTG_BR (RTG_TH + 2 + 14 + 16)        // 48 rows: offsets -14 .. +16 around the 18 determinant rows
+#define RTG_BC (RTG_TW + 2 + 14 + 16)        // 96 columns
+#define RTG_DET_THREADS 256
 // persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
 // with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
 #define RT_DET_GRID 4093
-#ifndef RT_DET_LDS
-#define RT_DET_LDS 1
+#ifndef RTG_DET_LDS
+#define RTG_DET_LDS 1
 #endif
-__global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(RTG_DET_THREADS) void rt_det_mask_general_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
 {
-    __shared__ double det[2][RT_TH + 2][RT_TW + 2];
-#if RT_DET_LDS
-    __shared__ double sblk[RT_BR * RT_BC];
+    __shared__ double det[2][RTG_TH + 2][RTG_TW + 2];
+#if RTG_DET_LDS
+    __shared__ double sblk[RTG_BR * RTG_BC];
 #endif
     // persistent-style grid: the number of live slots is known only on the device, and two million empty workgroups per
     // chunk cost more to dispatch than the whole tracking step
@@ -166,56 +321,56 @@ __global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, i
     const int ls = work / per, trem = work - ls * per;
     const int W = a.W, H = a.W;
     const double *S = a.S + (int64_t)ls * W * W;
-    const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW, t = threadIdx.x;
+    const int r0 = (trem / tiles_x) * RTG_TH, c0 = (trem % tiles_x) * RTG_TW, t = threadIdx.x;
     __syncthreads();
     // the 18 x 66 determinants of a tile read the integral image at rows r0-15 .. r0+32 and columns c0-15 .. c0+80 (box size
     // 30: offsets -14 .. +16).  Staging that 48 x 96 block in LDS was measured and rejected: 150 us per detection at 2 and at 4
     // waves per SIMD against 142 us for L1 reads at full occupancy
-    const bool interior = r0 >= RT_HALO && r0 - RT_HALO + RT_BR <= H && c0 >= RT_HALO && c0 - RT_HALO + RT_BC <= W && a.size1 == 15 && a.size2 == 30;
+    const bool interior = r0 >= RTG_HALO && r0 - RTG_HALO + RTG_BR <= H && c0 >= RTG_HALO && c0 - RTG_HALO + RTG_BC <= W && a.size1 == 15 && a.size2 == 30;
     // outside the image the 3x3x3 footprint sees nothing that could exceed v (mode = 'constant', 0 < threshold < v)
-#if RT_DET_LDS
+#if RTG_DET_LDS
     if (a.size1 == 15 && a.size2 == 30) {
         // stage the 48 x 96 block of the integral image once (source indices clipped at the image border: a clipped corner index
         // never leaves rows r0-15 .. r0+32 / columns c0-15 .. c0+80); then every thread walks its positions with the corner loads
         // of the NEXT determinant in flight while the arithmetic of the current one runs (layer 15, layer 30, layer 15, ...)
-        for (int i = t; i < RT_BR * RT_BC; i += RT_DET_THREADS) {
-            const int rr = i / RT_BC, cc = i - rr * RT_BC;
-            sblk[i] = interior ? S[(int64_t)(r0 - RT_HALO + rr) * W + (c0 - RT_HALO + cc)]
-                               : S[(int64_t)clipi(r0 - RT_HALO + rr, 0, H - 1) * W + clipi(c0 - RT_HALO + cc, 0, W - 1)];
+        for (int i = t; i < RTG_BR * RTG_BC; i += RTG_DET_THREADS) {
+            const int rr = i / RTG_BC, cc = i - rr * RTG_BC;
+            sblk[i] = interior ? S[(int64_t)(r0 - RTG_HALO + rr) * W + (c0 - RTG_HALO + cc)]
+                               : S[(int64_t)clipi(r0 - RTG_HALO + rr, 0, H - 1) * W + clipi(c0 - RTG_HALO + cc, 0, W - 1)];
         }
         __syncthreads();
-        constexpr int NPOS = (RT_TH + 2) * (RT_TW + 2);
+        constexpr int NPOS = (RTG_TH + 2) * (RTG_TW + 2);
         auto sweep = [&](const auto &acc) {
-            int rr = t / (RT_TW + 2), cc = t - rr * (RT_TW + 2);
+            int rr = t / (RTG_TW + 2), cc = t - rr * (RTG_TW + 2);
             double va[32], vb[32];
             if (t < NPOS) hessian_corners<15>(acc, r0 + rr - 1, c0 + cc - 1, va);
-            for (int i = t; i < NPOS; i += RT_DET_THREADS) {
+            for (int i = t; i < NPOS; i += RTG_DET_THREADS) {
                 const int r = r0 + rr - 1, c = c0 + cc - 1;
                 hessian_corners<30>(acc, r, c, vb);
                 double d0 = hessian_from_corners<15>(va);
-                int nr = rr + RT_DET_THREADS / (RT_TW + 2), nc = cc + RT_DET_THREADS % (RT_TW + 2);
-                if (nc >= RT_TW + 2) { nc -= RT_TW + 2; nr++; }
-                if (i + RT_DET_THREADS < NPOS) hessian_corners<15>(acc, r0 + nr - 1, c0 + nc - 1, va);
+                int nr = rr + RTG_DET_THREADS / (RTG_TW + 2), nc = cc + RTG_DET_THREADS % (RTG_TW + 2);
+                if (nc >= RTG_TW + 2) { nc -= RTG_TW + 2; nr++; }
+                if (i + RTG_DET_THREADS < NPOS) hessian_corners<15>(acc, r0 + nr - 1, c0 + nc - 1, va);
                 double d1 = hessian_from_corners<30>(vb);
                 if (r < 0 || r >= H || c < 0 || c >= W) { d0 = 0.0; d1 = 0.0; }     // outside the image: nothing that could exceed a maximum
                 det[0][rr][cc] = d0; det[1][rr][cc] = d1;
                 rr = nr; cc = nc;
             }
         };
-        if (interior) sweep(DohLdsAcc<RT_BC>{sblk, r0 - RT_HALO, c0 - RT_HALO});
-        else sweep(DohLdsClipAcc<RT_BC>{sblk, r0 - RT_HALO, c0 - RT_HALO, H, W});
+        if (interior) sweep(DohLdsAcc<RTG_BC>{sblk, r0 - RTG_HALO, c0 - RTG_HALO});
+        else sweep(DohLdsClipAcc<RTG_BC>{sblk, r0 - RTG_HALO, c0 - RTG_HALO, H, W});
     } else
 #endif
     {
         // general box sizes (not used by the engine's fixed parameters): 2 x 18 x 66 = 2376 (layer, row, column) items
-        constexpr int NPOS = (RT_TH + 2) * (RT_TW + 2);
+        constexpr int NPOS = (RTG_TH + 2) * (RTG_TW + 2);
         int l = t / NPOS, rem = t - l * NPOS;
-        int rr = rem / (RT_TW + 2), cc = rem - rr * (RT_TW + 2);
-        for (int i = t; i < 2 * NPOS; i += RT_DET_THREADS) {
+        int rr = rem / (RTG_TW + 2), cc = rem - rr * (RTG_TW + 2);
+        for (int i = t; i < 2 * NPOS; i += RTG_DET_THREADS) {
             const int r = r0 + rr - 1, c = c0 + cc - 1;
             double v = 0.0;
             if (r >= 0 && r < H && c >= 0 && c < W) {
-#if !RT_DET_LDS
+#if !RTG_DET_LDS
                 if (a.size1 == 15 && a.size2 == 30) {
                     if (interior) { const DohGlobalInteriorAcc ga = {S, W}; v = l == 0 ? hessian_det_fixed<15>(ga, r, c) : hessian_det_fixed<30>(ga, r, c); }
                     else { const DohGlobalAcc gc = {S, H, W}; v = l == 0 ? hessian_det_fixed<15>(gc, r, c) : hessian_det_fixed<30>(gc, r, c); }
@@ -224,15 +379,15 @@ __global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, i
                 v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
             }
             det[l][rr][cc] = v;
-            rr += RT_DET_THREADS / (RT_TW + 2); cc += RT_DET_THREADS % (RT_TW + 2);
-            if (cc >= RT_TW + 2) { cc -= RT_TW + 2; rr++; }
-            if (rr >= RT_TH + 2) { rr -= RT_TH + 2; l++; }
+            rr += RTG_DET_THREADS / (RTG_TW + 2); cc += RTG_DET_THREADS % (RTG_TW + 2);
+            if (cc >= RTG_TW + 2) { cc -= RTG_TW + 2; rr++; }
+            if (rr >= RTG_TH + 2) { rr -= RTG_TH + 2; l++; }
         }
     }
     __syncthreads();
     const int cc = t & 63, rb = t >> 6;
-    for (int k = 0; k < RT_TH / (RT_DET_THREADS / 64); k++) {
-        const int rr = rb * (RT_TH / (RT_DET_THREADS / 64)) + k, r = r0 + rr, c = c0 + cc;
+    for (int k = 0; k < RTG_TH / (RTG_DET_THREADS / 64); k++) {
+        const int rr = rb * (RTG_TH / (RTG_DET_THREADS / 64)) + k, r = r0 + rr, c = c0 + cc;
         if (r >= H || c >= W) continue;
         // 3x3x3 footprint = the 18 determinants around the pixel in both layers: one maximum, loaded without branches
         // (a short-circuit chain of 36 dependent LDS reads per pixel was 3/4 of this kernel's time)
@@ -248,6 +403,90 @@ __global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, i
         a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
         if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
     }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3: determinants + maxima
+// The engine's box sizes (15, 30).  A workgroup of 8 waves owns a 30 x 62 pixel tile: with the one-pixel halo of the 3x3x3 maxima
+// that is a 32 x 64 grid of determinant positions (wave = row, lane = column, four rows per wave), which read the integral image at
+// rows r0-15 .. r0+46 and columns c0-15 .. c0+78 (box size 30: offsets -14 .. +16): that 62 x 94 block is staged in LDS once.
+// Determinants come from hessian_det_pruned (doh_common.h): a position whose dxx*dyy does not exceed the threshold skips the dxy
+// boxes.  Only max(layer 15, layer 30) per position goes to LDS; a pixel's own two determinants stay in registers, and the 3 x 3
+// neighbourhood is read only by waves that hold a candidate.
+#define RT_TH 30
+#define RT_TW 62
+#define RT_PR (RT_TH + 2)                  // 32 position rows
+#define RT_PC (RT_TW + 2)                  // 64 position columns
+#define RT_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
+#define RT_BR (RT_PR + 14 + 16)            // 62 rows
+#define RT_BC (RT_PC + 14 + 16)            // 94 columns
+#define RT_DET_THREADS 512
+// persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
+// with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
+#define RT_DET_GRID 4093
+__global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
+{
+    __shared__ double sblk[RT_BR * RT_BC];
+    __shared__ double m2[RT_PR][RT_PC];
+    const int nact = min(P, max(0, *a.rt_n - first));
+    const int per = tiles_x * tiles_y;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int W = a.W, H = a.W;
+    const double thr = a.threshold;
+    for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
+        const int ls = work / per, trem = work - ls * per;
+        const double *S = a.S + (int64_t)ls * W * W;
+        const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW;
+        const int rbase = r0 - RT_HALO, cbase = c0 - RT_HALO;
+        const bool interior = rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W;
+        __syncthreads();                                                   // the previous tile's readers are done
+        // stage the block (source indices clipped at the image border: skimage's clipped corner indices never leave it)
+        {
+            const int ca = clipi(cbase + lane, 0, W - 1), cb = clipi(cbase + 64 + lane, 0, W - 1);
+            for (int rr = wave; rr < RT_BR; rr += RT_DET_THREADS / 64) {
+                const double *row = S + (int64_t)clipi(rbase + rr, 0, H - 1) * W;
+                sblk[rr * RT_BC + lane] = row[ca];
+                if (lane < RT_BC - 64) sblk[rr * RT_BC + 64 + lane] = row[cb];
+            }
+        }
+        __syncthreads();
+        double d0[4], d1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
+            double u0 = 0.0, u1 = 0.0;                                     // outside the image: nothing that could exceed a maximum
+            if (r >= 0 && r < H && c >= 0 && c < W) {
+                if (interior) {
+                    const DohLdsAcc<RT_BC> acc = {sblk, rbase, cbase};
+                    u0 = hessian_det_pruned<15>(acc, r, c, thr);
+                    u1 = hessian_det_pruned<30>(acc, r, c, thr);
+                } else {
+                    const DohLdsClipAcc<RT_BC> acc = {sblk, rbase, cbase, H, W};
+                    u0 = hessian_det_pruned<15>(acc, r, c, thr);
+                    u1 = hessian_det_pruned<30>(acc, r, c, thr);
+                }
+            }
+            d0[k] = u0; d1[k] = u1;
+            m2[rr][lane] = u1 > u0 ? u1 : u0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
+            if (rr < 1 || rr > RT_TH || lane < 1 || lane > RT_TW || r >= H || c >= W) continue;
+            uint32_t bits = 0;
+            if (d0[k] > thr || d1[k] > thr) {
+                // 3x3x3 footprint = the 9 per-position maxima around the pixel (the pixel's own included)
+                double m = m2[rr][lane];
+#pragma unroll
+                for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+                    for (int dc = -1; dc <= 1; dc++) { const double u = m2[rr + dr][lane + dc]; m = u > m ? u : m; }
+                bits = ((d0[k] > thr && !(m > d0[k])) ? 1u : 0u) | ((d1[k] > thr && !(m > d1[k])) ? 2u : 0u);
+            }
+            a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
+            if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
+        }
     }
 }
 
@@ -506,6 +745,11 @@ __global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
+hipError_t retrack_init()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(rt_integral_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RI_LDS_BYTES);
+}
+
 hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
 {
     const int W = a.W, R = a.slots;
@@ -513,12 +757,20 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
         const int P = min(R, B - first);
         hipError_t e = hipMemsetAsync(a.row_cnt, 0, sizeof(int32_t) * (size_t)P * (W + 1), st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
+        if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
+        else {
+            hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
+            hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
+        }
         {
             const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
             const int64_t all = (int64_t)tx * ty * P;
-            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
+            if (a.size1 == 15 && a.size2 == 30)
+                hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
+            else {
+                const int gx = (W + RTG_TW - 1) / RTG_TW, gy = (W + RTG_TH - 1) / RTG_TH;
+                hipLaunchKernelGGL(rt_det_mask_general_kernel, dim3((unsigned)std::min<int64_t>((int64_t)P * gx * gy, RT_DET_GRID)), dim3(RTG_DET_THREADS), 0, st, a, first, P, gx, gy);
+            }
         }
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
@@ -543,6 +795,8 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
 {
     const int W = a.W;
     if (which == 0) {
+        hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
+    } else if (which == 2) {
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, 0);
     } else {
