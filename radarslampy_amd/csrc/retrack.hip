@@ -420,54 +420,85 @@ __global__ __launch_bounds__(RTG_DET_THREADS) void rt_det_mask_general_kernel(Rt
 #define RT_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
 #define RT_BR (RT_PR + 14 + 16)            // 62 rows
 #define RT_BC (RT_PC + 14 + 16)            // 94 columns
+#define RT_BP 96                           // LDS pitch of the block: 3 x 32 staging columns (94 used)
 #define RT_DET_THREADS 512
 // persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
 // with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
 #define RT_DET_GRID 4093
-__global__ __launch_bounds__(RT_DET_THREADS) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
 {
-    __shared__ double sblk[RT_BR * RT_BC];
+    __shared__ double sblk[RT_BR * RT_BP];
     __shared__ double m2[RT_PR][RT_PC];
     const int nact = min(P, max(0, *a.rt_n - first));
     const int per = tiles_x * tiles_y;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int W = a.W, H = a.W;
     const double thr = a.threshold;
-    for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
+    // the block of a tile travels global -> registers -> LDS; the loads of the NEXT tile are issued before the arithmetic of the
+    // current one, so that the L2 latency (69 % TCP pending stall when staged in place) hides behind it.  Thread t stages rows
+    // (t / 32) + 16 q, columns (t % 32) + 32 p: no division, and in interior tiles every offset is an immediate
+    double stage[4][3];
+    const int srow = t >> 5, scol = t & 31;
+    auto fetch = [&](int work) {
         const int ls = work / per, trem = work - ls * per;
         const double *S = a.S + (int64_t)ls * W * W;
+        const int rbase = (trem / tiles_x) * RT_TH - RT_HALO, cbase = (trem % tiles_x) * RT_TW - RT_HALO;
+        if (rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W) {
+            const double *q = S + (int64_t)(rbase + srow) * W + cbase + scol;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++)
+                if (qq < 3 || srow + 48 < RT_BR) {
+                    stage[qq][0] = q[qq * 16 * W]; stage[qq][1] = q[qq * 16 * W + 32];
+                    if (scol + 64 < RT_BC) stage[qq][2] = q[qq * 16 * W + 64];
+                }
+        } else {
+            // source indices clipped at the image border: skimage's clipped corner indices never leave the block
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const double *q = S + (int64_t)clipi(rbase + srow + 16 * qq, 0, H - 1) * W;
+#pragma unroll
+                for (int pp = 0; pp < 3; pp++) stage[qq][pp] = q[clipi(cbase + scol + 32 * pp, 0, W - 1)];
+            }
+        }
+    };
+    if ((int)blockIdx.x < nact * per) fetch(blockIdx.x);
+    for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
+        const int ls = work / per, trem = work - ls * per;
         const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW;
         const int rbase = r0 - RT_HALO, cbase = c0 - RT_HALO;
         const bool interior = rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W;
         __syncthreads();                                                   // the previous tile's readers are done
-        // stage the block (source indices clipped at the image border: skimage's clipped corner indices never leave it)
-        {
-            const int ca = clipi(cbase + lane, 0, W - 1), cb = clipi(cbase + 64 + lane, 0, W - 1);
-            for (int rr = wave; rr < RT_BR; rr += RT_DET_THREADS / 64) {
-                const double *row = S + (int64_t)clipi(rbase + rr, 0, H - 1) * W;
-                sblk[rr * RT_BC + lane] = row[ca];
-                if (lane < RT_BC - 64) sblk[rr * RT_BC + 64 + lane] = row[cb];
-            }
-        }
-        __syncthreads();
-        double d0[4], d1[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
-            double u0 = 0.0, u1 = 0.0;                                     // outside the image: nothing that could exceed a maximum
-            if (r >= 0 && r < H && c >= 0 && c < W) {
-                if (interior) {
-                    const DohLdsAcc<RT_BC> acc = {sblk, rbase, cbase};
-                    u0 = hessian_det_pruned<15>(acc, r, c, thr);
-                    u1 = hessian_det_pruned<30>(acc, r, c, thr);
-                } else {
-                    const DohLdsClipAcc<RT_BC> acc = {sblk, rbase, cbase, H, W};
+        for (int qq = 0; qq < 4; qq++)
+            if (qq < 3 || srow + 48 < RT_BR) {
+#pragma unroll
+                for (int pp = 0; pp < 3; pp++) sblk[(srow + 16 * qq) * RT_BP + scol + 32 * pp] = stage[qq][pp];
+            }
+        __syncthreads();
+        if (work + (int)gridDim.x < nact * per) fetch(work + gridDim.x);
+        double d0[4], d1[4];
+        if (interior) {
+            const DohLdsAcc<RT_BP> acc = {sblk, rbase, cbase};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
+                d0[k] = hessian_det_pruned<15>(acc, r, c, thr);
+                d1[k] = hessian_det_pruned<30>(acc, r, c, thr);
+                m2[rr][lane] = d1[k] > d0[k] ? d1[k] : d0[k];
+            }
+        } else {
+            const DohLdsClipAcc<RT_BP> acc = {sblk, rbase, cbase, H, W};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
+                double u0 = 0.0, u1 = 0.0;                                 // outside the image: nothing that could exceed a maximum
+                if (r >= 0 && r < H && c >= 0 && c < W) {
                     u0 = hessian_det_pruned<15>(acc, r, c, thr);
                     u1 = hessian_det_pruned<30>(acc, r, c, thr);
                 }
+                d0[k] = u0; d1[k] = u1;
+                m2[rr][lane] = u1 > u0 ? u1 : u0;
             }
-            d0[k] = u0; d1[k] = u1;
-            m2[rr][lane] = u1 > u0 ? u1 : u0;
         }
         __syncthreads();
 #pragma unroll
