@@ -15,7 +15,8 @@ FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-ffp-contract=
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 # per-file additions.  retrack.hip: its determinant kernel lives on 8-byte LDS reads, and the backend's load/store optimizer pairs them
 # into ds_read2_b64, which moves 8 bytes per lane at HALF the rate of ds_read_b64 on gfx950 (128 against 256 B/clk per CU)
-EXTRA = {"retrack.hip": ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]}
+NO_PAIRING = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
+EXTRA = {"retrack.hip": NO_PAIRING}
 
 
 def _sources():

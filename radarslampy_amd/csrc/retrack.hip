@@ -60,10 +60,20 @@ __global__ __launch_bounds__(256) void rt_collect_kernel(const roam_lane_result 
 // ------------------------------------------------------------------------------------------------ K1 / K2: integral image
 __device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dmul_rn((double)k, 1.0 / 255.0); }
 
+// Two ways to the integral image, chosen on the device by the number of detections of the chunk (only the device knows it):
+//   * rt_integral_kernel (below): one workgroup per detection, the image written once - 19 us per detection at 512, but a chain of
+//     1016 dependent phases per detection: 9.7 ms per chunk whatever its size (measured also with taps and map words prefetched one
+//     and two phases ahead: no gain - the byte gathers are bound by the texture addresser's throughput, not by latency)
+//   * rt_integ_cols_kernel + rt_integ_rows_kernel: thousands of threads per detection, three times the traffic - 47 us per detection
+//     at scale, 1.7 ms for one alone
+// Both are launched; the one whose regime it is not returns at once.
+#define RI_MIN_DETECTIONS 200
+__device__ __forceinline__ bool rt_one_sweep(const RtArgs &a, int first) { return a.W <= 2048 && *a.rt_n - first >= RI_MIN_DETECTIONS; }
+
 __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 {
     const int ls = blockIdx.y, slot = first + ls;
-    if (slot >= *a.rt_n) return;
+    if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
     const int c = blockIdx.x * 256 + threadIdx.x, W = a.W;
     if (c >= W) return;
     const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 {
     __shared__ double tile[64][RT_CW + 1];
     const int ls = blockIdx.y, slot = first + ls;
-    if (slot >= *a.rt_n) return;
+    if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
     const int W = a.W, H = a.W;
     double *S = a.S + (int64_t)ls * W * W;
     const int lane = threadIdx.x, r0 = blockIdx.x * 64;
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 // The tiles are double-buffered, so that between two barriers the column waves run C(i-1) and A(i+1) while the row wave runs B(i):
 // A is bound by load latency, B by the latency of 64 x RI_WAVES dependent float64 additions, and they hide each other.
 // Both cumulative sums keep NumPy's sequential order; the float64 image is written ONCE (32.8 MB per detection instead of the
-// 98.6 MB moved by the two-pass kernels above, which stay for image sizes above 2048).
+// 98.6 MB moved by the two-pass kernels above, which stay for small chunks - see rt_one_sweep - and for image sizes above 2048).
 #define RI_ROWS 16
 #define RI_WAVES 4
 #define RI_GROUPS (2048 / (64 * RI_WAVES))
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 {
     extern __shared__ double ri_lds[];
     const int ls = blockIdx.x, slot = first + ls;
-    if (slot >= *a.rt_n) return;
+    if (slot >= *a.rt_n || !rt_one_sweep(a, first)) return;
     typedef double Tile[RI_ROWS][65];
     Tile *tiles = reinterpret_cast<Tile *>(ri_lds);                        // [2][RI_WAVES]
     const int W = a.W, H = a.W, t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -543,6 +553,7 @@ __global__ __launch_bounds__(256) void rt_emit_kernel(RtArgs a, int first)
     int pos = inc - c, total = 0;
     for (int i = 0; i < 4; i++) { if (i < w) pos += sh[i]; total += sh[i]; }
     for (int r = lo; r < hi; r++) { row_off[r] = pos; pos += rc[r]; }
+    if (t == 255) row_off[H] = total;
     __syncthreads();
     if (t == 0) a.cand_n[ls] = total;
     const double *S = a.S + (int64_t)ls * W * W;
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(256) void rt_emit_kernel(RtArgs a, int first)
     double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
     // rows with maxima: wave w takes rows w, w+4, ...; a lane owns 32 consecutive pixels, order = (col, layer) ascending
     for (int r = w; r < H; r += 4) {
-        if (rc[r] == 0) continue;
+        if (row_off[r + 1] == row_off[r]) continue;         // (from LDS: a global read per row made this loop 1.2 ms of pure latency)
         const int cb = lane * 32;
         int cnt = 0;
         uint32_t m0 = 0, m1 = 0;                            // bit k: pixel cb + k has a maximum in layer 0 / 1
@@ -578,6 +589,7 @@ __global__ __launch_bounds__(256) void rt_emit_kernel(RtArgs a, int first)
 }
 
 // ------------------------------------------------------------------------------------------------ K5: blob bookkeeping
+#define RT_PL 3328                      // (what the 64 KB of static LDS leave)
 struct RtBlobLds {
     int16_t xy[2 * BP_MAX_PTS];       // [row, col] in response order
     int16_t idx[BP_MAX_PTS];          // cKDTree.indices, later the aquicksort permutation
@@ -588,6 +600,7 @@ struct RtBlobLds {
     BpTracker tr;
     uint16_t tabA[2048], tabB[8192];
     uint32_t ovbits[(BP_LDS_PAIRS + 31) / 32 + 1];
+    uint32_t pl[RT_PL];               // the pairs, when they fit: the sequential set-order pass reads them one by one
     int vals[8];
 };
 
@@ -656,20 +669,20 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
             }
             const uint64_t bal = __ballot(ok);
             const int o = np + __popcll(bal & ((1ull << lane) - 1ull));
-            if (ok && o < BP_MAX_PAIRS) pairs[o] = bp_pack(pi, pj);
+            if (ok && o < BP_MAX_PAIRS) { pairs[o] = bp_pack(pi, pj); if (o < RT_PL) L.pl[o] = bp_pack(pi, pj); }
             np += __popcll(bal);
         }
     }
     if (np > BP_MAX_PAIRS) { flags |= RT_F_PAIR_OVERFLOW; np = BP_MAX_PAIRS; }
     __syncthreads();
     // 4. which pairs overlap by more than 0.5 (original sigmas: a pair with a pruned member never changes anything)
-    const bool lds_set = np <= BP_LDS_PAIRS;
+    const bool lds_set = np <= BP_LDS_PAIRS, lds_pl = np <= RT_PL;
     uint32_t *ovb = lds_set ? L.ovbits : a.ovbits + (int64_t)ls * ((BP_MAX_PAIRS + 31) / 32 + 1);
     for (int w0 = 0; w0 < np; w0 += 64) {
         const int k = w0 + lane;
         bool ov = false;
         if (k < np) {
-            const uint32_t pr = pairs[k];
+            const uint32_t pr = lds_pl ? L.pl[k] : pairs[k];
             const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
             ov = bp_overlaps((double)L.xy[2 * i], (double)L.xy[2 * i + 1], L.lay[i] == 2 ? a.sigma2 : a.sigma1,
                              (double)L.xy[2 * j], (double)L.xy[2 * j + 1], L.lay[j] == 2 ? a.sigma2 : a.sigma1, 0.5);
@@ -682,19 +695,53 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     uint16_t *order = a.order + (int64_t)ls * (BP_MAX_PAIRS + 1);
     if (lane == 0) {
         int m;
-        if (lds_set) m = bp_pyset_order(pairs, np, L.tabA, 2048, L.tabB, 8192, order);
+        if (lds_pl) m = bp_pyset_order(L.pl, np, L.tabA, 2048, L.tabB, 8192, order);
+        else if (lds_set) m = bp_pyset_order(pairs, np, L.tabA, 2048, L.tabB, 8192, order);
         else {
             uint16_t *big = a.bigtab + (int64_t)ls * 2 * 131072;
             m = bp_pyset_order(pairs, np, big, 131072, big + 131072, 131072, order);
         }
         if (m != np) flags |= RT_F_PAIR_OVERFLOW;
-        for (int k = 0; k < (m < 0 ? 0 : m); k++) {
+        L.vals[2] = m < 0 ? 0 : m;
+    }
+    __syncthreads();
+    // the overlapping pairs in set order, gathered by the whole wave (the hash tables are free again: 4096 pairs fit in tabB);
+    // the sequential pass then walks LDS only - one lane chasing order[k] -> pairs[q] through global memory was 2/3 of this kernel
+    const int m = L.vals[2];
+    uint32_t *cl = reinterpret_cast<uint32_t *>(L.tabB);
+    int ncl = 0;
+    for (int k0 = 0; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        bool ov = false;
+        uint32_t pr = 0;
+        if (k < m) {
             const int q = order[k];
-            if (!((ovb[q >> 5] >> (q & 31)) & 1u)) continue;
-            const uint32_t pr = pairs[q];
-            const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
-            if (L.lay[i] == 0 || L.lay[j] == 0) continue;
-            if (L.lay[i] > L.lay[j]) L.lay[j] = 0; else L.lay[i] = 0;     // sigma_i > sigma_j ? prune j : prune i (ties: i)
+            ov = (ovb[q >> 5] >> (q & 31)) & 1u;
+            if (ov) pr = lds_pl ? L.pl[q] : pairs[q];
+        }
+        const uint64_t bal = __ballot(ov);
+        const int o = ncl + __popcll(bal & ((1ull << lane) - 1ull));
+        if (ov && o < 4096) cl[o] = pr;
+        ncl += __popcll(bal);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        if (ncl <= 4096) {
+            for (int k = 0; k < ncl; k++) {
+                const uint32_t pr = cl[k];
+                const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
+                if (L.lay[i] == 0 || L.lay[j] == 0) continue;
+                if (L.lay[i] > L.lay[j]) L.lay[j] = 0; else L.lay[i] = 0;     // sigma_i > sigma_j ? prune j : prune i (ties: i)
+            }
+        } else {
+            for (int k = 0; k < m; k++) {
+                const int q = order[k];
+                if (!((ovb[q >> 5] >> (q & 31)) & 1u)) continue;
+                const uint32_t pr = pairs[q];
+                const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
+                if (L.lay[i] == 0 || L.lay[j] == 0) continue;
+                if (L.lay[i] > L.lay[j]) L.lay[j] = 0; else L.lay[i] = 0;
+            }
         }
         // survivors in response order (reuse xy / lay in place), sorted by sigma with NumPy 1.22's tie order
         int mb = 0;
@@ -789,10 +836,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
         hipError_t e = hipMemsetAsync(a.row_cnt, 0, sizeof(int32_t) * (size_t)P * (W + 1), st);
         if (e != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
-        else {
-            hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
-            hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
-        }
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
         {
             const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
             const int64_t all = (int64_t)tx * ty * P;
@@ -827,7 +872,6 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
     const int W = a.W;
     if (which == 0) {
         hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
-    } else if (which == 2) {
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, 0);
     } else {
