@@ -175,7 +175,7 @@ typedef struct roam_engine_cfg {
     double sigma5[5];
     int32_t retrack_on_device;/* 1: lanes that run out of features (<= 60 inliers, RawROAMSystem.py:250-271) re-detect
                                  (appendNewFeatures: DoH blobs + ANMS, getFeatures.py:74-118) inside roam_engine_step */
-    int32_t retrack_slots;    /* lanes whose detection scratch (37 MB each) is resident at once; 0 = min(lanes, 512) */
+    int32_t retrack_slots;    /* lanes whose detection scratch (33 MB each) is resident at once; 0 = min(lanes, 512) */
 } roam_engine_cfg;
 
 typedef struct roam_lane_result {

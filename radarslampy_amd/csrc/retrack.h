@@ -22,11 +22,9 @@ struct RtArgs {
     int32_t *rt_n, *rt_lane, *rt_scan;
     // per-slot scratch (slots entries each)
     double *S;                      // W x W float64 integral image
-    uint8_t *mask;                  // W x W: bit s = 3x3x3 maximum in layer s
-    int32_t *row_cnt;               // W + 1
-    uint32_t *cand_rc;              // BP_MAX_PTS: row << 16 | col << 2 | layer
+    uint32_t *cand_rc;              // BP_MAX_PTS: row << 16 | col << 2 | layer (appended by the determinant kernel, sorted by rt_emit_kernel)
     double *cand_val;               // BP_MAX_PTS
-    int32_t *cand_n;
+    int32_t *cand_n;                // maxima found (may exceed BP_MAX_PTS: RT_F_CAND_OVERFLOW, the kept subset is then arbitrary)
     BpTask *tasks;                  // BP_MAX_TASKS
     uint32_t *pairs;                // BP_MAX_PAIRS + 1
     uint16_t *order;                // BP_MAX_PAIRS + 1

@@ -304,6 +304,23 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
     }
 }
 
+// A maximum goes straight onto the detection's candidate list, in whatever order the workgroups get there; rt_emit_kernel sorts the
+// list into the reference's (row, column, layer) order.  (Round 2's first version wrote a 1-byte mask per pixel plus row counts
+// and had the emission kernel scan the mask and compute every candidate's determinant again from global memory: 4 MB more
+// traffic per detection and 1.1-1.7 ms of latency per chunk.)
+__device__ __forceinline__ void rt_push_maxima(const RtArgs &a, int ls, int r, int c, uint32_t bits, double v0, double v1)
+{
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+        if ((bits >> l) & 1u) {
+            const int o = atomicAdd(&a.cand_n[ls], 1);
+            if (o < BP_MAX_PTS) {
+                a.cand_rc[(int64_t)ls * BP_MAX_PTS + o] = ((uint32_t)r << 16) | ((uint32_t)c << 2) | (uint32_t)(l + 1);
+                a.cand_val[(int64_t)ls * BP_MAX_PTS + o] = l ? v1 : v0;
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ K3 (general box sizes): determinants + maxima
 #define RTG_TH 16
 #define RTG_TW 64
@@ -410,8 +427,7 @@ __global__ __launch_bounds__(RTG_DET_THREADS) void rt_det_mask_general_kernel(Rt
                 for (int dc = 0; dc < 3; dc++) { const double u = det[ll][rr + dr][cc + dc]; m = u > m ? u : m; }
         const double v0 = det[0][rr + 1][cc + 1], v1 = det[1][rr + 1][cc + 1];
         const uint32_t bits = ((v0 > a.threshold && !(m > v0)) ? 1u : 0u) | ((v1 > a.threshold && !(m > v1)) ? 2u : 0u);
-        a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
-        if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
+        if (bits) rt_push_maxima(a, ls, r, c, bits, v0, v1);
     }
     }
 }
@@ -525,66 +541,32 @@ __global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a
                     for (int dc = -1; dc <= 1; dc++) { const double u = m2[rr + dr][lane + dc]; m = u > m ? u : m; }
                 bits = ((d0[k] > thr && !(m > d0[k])) ? 1u : 0u) | ((d1[k] > thr && !(m > d1[k])) ? 2u : 0u);
             }
-            a.mask[(int64_t)ls * W * W + (int64_t)r * W + c] = (uint8_t)bits;
-            if (bits) atomicAdd(&a.row_cnt[(int64_t)ls * (W + 1) + r], (int)__popc(bits));
+            if (bits) rt_push_maxima(a, ls, r, c, bits, d0[k], d1[k]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ K4: ordered candidates
+// the candidates of a detection (at most BP_MAX_PTS are kept) sorted by (row, column, layer): keys are unique, so a key's rank is
+// the number of smaller keys - every thread counts for its keys against the whole list in LDS (broadcast reads)
 __global__ __launch_bounds__(256) void rt_emit_kernel(RtArgs a, int first)
 {
-    __shared__ int sh[8];
-    __shared__ int row_off[2048 + 8];
+    __shared__ uint32_t key[BP_MAX_PTS];
+    __shared__ double val[BP_MAX_PTS];
     const int ls = blockIdx.x, slot = first + ls;
     if (slot >= *a.rt_n) return;
-    const int W = a.W, H = a.W, t = threadIdx.x;
-    const int32_t *rc = a.row_cnt + (int64_t)ls * (W + 1);
-    // exclusive scan of the H row counts (H <= 2048)
-    const int items = (H + 255) / 256, lo = t * items, hi = min(lo + items, H);
-    int c = 0;
-    for (int r = lo; r < hi; r++) c += rc[r];
-    const int lane = t & 63, w = t >> 6;
-    int inc = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int n = __shfl_up(inc, d); if (lane >= d) inc += n; }
-    if (lane == 63) sh[w] = inc;
-    __syncthreads();
-    int pos = inc - c, total = 0;
-    for (int i = 0; i < 4; i++) { if (i < w) pos += sh[i]; total += sh[i]; }
-    for (int r = lo; r < hi; r++) { row_off[r] = pos; pos += rc[r]; }
-    if (t == 255) row_off[H] = total;
-    __syncthreads();
-    if (t == 0) a.cand_n[ls] = total;
-    const double *S = a.S + (int64_t)ls * W * W;
-    const uint8_t *mk = a.mask + (int64_t)ls * W * W;
+    const int t = threadIdx.x;
+    const int n = min(a.cand_n[ls], BP_MAX_PTS);
     uint32_t *crc = a.cand_rc + (int64_t)ls * BP_MAX_PTS;
     double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
-    // rows with maxima: wave w takes rows w, w+4, ...; a lane owns 32 consecutive pixels, order = (col, layer) ascending
-    for (int r = w; r < H; r += 4) {
-        if (row_off[r + 1] == row_off[r]) continue;         // (from LDS: a global read per row made this loop 1.2 ms of pure latency)
-        const int cb = lane * 32;
-        int cnt = 0;
-        uint32_t m0 = 0, m1 = 0;                            // bit k: pixel cb + k has a maximum in layer 0 / 1
-        for (int k = 0; k < 32; k++) {
-            const int cc = cb + k;
-            const uint32_t b = cc < W ? mk[(int64_t)r * W + cc] : 0;
-            m0 |= (b & 1u) << k; m1 |= ((b >> 1) & 1u) << k;
-        }
-        cnt = __popc(m0) + __popc(m1);
-        int pre = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { int n = __shfl_up(pre, d); if (lane >= d) pre += n; }
-        int o = row_off[r] + pre - cnt;
-        for (int k = 0; k < 32; k++)
-            for (int l = 0; l < 2; l++)
-                if (((l ? m1 : m0) >> k) & 1u) {
-                    if (o < BP_MAX_PTS) {
-                        crc[o] = ((uint32_t)r << 16) | ((uint32_t)(cb + k) << 2) | (uint32_t)(l + 1);
-                        cval[o] = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, cb + k);
-                    }
-                    o++;
-                }
+    for (int i = t; i < n; i += 256) { key[i] = crc[i]; val[i] = cval[i]; }
+    __syncthreads();
+    for (int i = t; i < n; i += 256) {
+        const uint32_t k = key[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += key[j] < k ? 1 : 0;
+        crc[rank] = k;
+        cval[rank] = val[i];
     }
 }
 
@@ -833,7 +815,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
     const int W = a.W, R = a.slots;
     for (int first = 0; first < B; first += R) {
         const int P = min(R, B - first);
-        hipError_t e = hipMemsetAsync(a.row_cnt, 0, sizeof(int32_t) * (size_t)P * (W + 1), st);
+        hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
         if (e != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
@@ -875,7 +857,7 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, 0);
     } else {
-        hipError_t e = hipMemsetAsync(a.row_cnt, 0, sizeof(int32_t) * (size_t)P * (W + 1), st);
+        hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
         if (e != hipSuccess) return e;
         const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
         const int64_t all = (int64_t)tx * ty * P;
