@@ -1124,8 +1124,8 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, which));
             const double npx = (double)e->W * e->W;
             // algorithmic bytes per detection: integral image (one sweep) = polar payload + 4-byte map word per pixel read, float64
-            // image written once; determinants + maxima = float64 image read once + 1 byte per pixel written
-            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 4.0 + npx * 8.0) : (npx * 8.0 + npx));
+            // image written once; determinants + maxima = float64 image read once (the candidates it writes are a few KB)
+            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 4.0 + npx * 8.0) : npx * 8.0);
         } else if (!strcmp(name, "pyramid")) {
             HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
             double rd = 0, wr = 0;
