@@ -14,13 +14,6 @@ struct DohGlobalAcc {
     __device__ __forceinline__ double at(int r, int c) const { return S[(int64_t)r * W + c]; }
 };
 
-struct DohGlobalInteriorAcc {            // interior pixels: no index leaves the image
-    const double *__restrict__ S; int W;
-    __device__ __forceinline__ int cr(int r) const { return r; }
-    __device__ __forceinline__ int cc(int c) const { return c; }
-    __device__ __forceinline__ double at(int r, int c) const { return S[r * W + c]; }
-};
-
 template <int PITCH>
 struct DohLdsAcc {                       // rows rbase.., columns cbase.. of the integral image, staged by the caller
     const double *blk; int rbase, cbase;
@@ -70,41 +63,7 @@ __device__ __forceinline__ double hessian_det_acc(const ACC &a, int size, int r,
     return __dsub_rn(__dmul_rn(dxx, dyy), __dmul_rn(0.81, __dmul_rn(dxy, dxy)));
 }
 
-// The same determinant split into its 32 corner loads and its arithmetic, so that a kernel can issue the loads of the NEXT
-// determinant before it does the arithmetic of the current one (software pipelining across work items).  Operation order and
-// rounding are those of hessian_det_acc.
-template <int SIZE, typename ACC>
-__device__ __forceinline__ void hessian_corners(const ACC &a, int r, int c, double (&v)[32])
-{
-    constexpr int s2 = (SIZE - 1) / 2, s3 = SIZE / 3, w = SIZE;
-    // {row, col, row extent, col extent} of the 8 boxes in the order tl, br, bl, tr, xx-mid, xx-side, yy-mid, yy-side
-    constexpr int B[8][4] = {{-s3, -s3, s3, s3}, {1, 1, s3, s3}, {-s3, 1, s3, s3}, {1, -s3, s3, s3},
-                             {-s3 + 1, -s2, 2 * s3 - 1, w}, {-s3 + 1, -(s3 / 2), 2 * s3 - 1, s3},
-                             {-s2, -s3 + 1, w, 2 * s3 - 1}, {-(s3 / 2), -s3 + 1, s3, 2 * s3 - 1}};
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int r0 = a.cr(r + B[k][0]), c0 = a.cc(c + B[k][1]), r1 = a.cr(r0 + B[k][2]), c1 = a.cc(c0 + B[k][3]);   // _integ's clipping (identity inside)
-        v[4 * k] = a.at(r0, c0); v[4 * k + 1] = a.at(r1, c1); v[4 * k + 2] = a.at(r0, c1); v[4 * k + 3] = a.at(r1, c0);
-    }
-}
-
-template <int SIZE>
-__device__ __forceinline__ double hessian_from_corners(const double (&v)[32])
-{
-    const double w_i = __ddiv_rn(__ddiv_rn(1.0, (double)SIZE), (double)SIZE);
-    double b[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) b[k] = fmax(__dsub_rn(__dsub_rn(__dadd_rn(v[4 * k], v[4 * k + 1]), v[4 * k + 2]), v[4 * k + 3]), 0.0);
-    double dxy = __dsub_rn(__dsub_rn(__dadd_rn(b[2], b[3]), b[0]), b[1]);       // bl + tr - tl - br
-    dxy = __dmul_rn(-dxy, w_i);
-    double dxx = __dsub_rn(b[4], __dmul_rn(3.0, b[5]));
-    dxx = __dmul_rn(-dxx, w_i);
-    double dyy = __dsub_rn(b[6], __dmul_rn(3.0, b[7]));
-    dyy = __dmul_rn(-dyy, w_i);
-    return __dsub_rn(__dmul_rn(dxx, dyy), __dmul_rn(0.81, __dmul_rn(dxy, dxy)));
-}
-
-// One box of the determinant (k = 0..7 in hessian_corners' order): skimage's _integ, clipping included.
+// One box of the determinant (k = 0..7: tl, br, bl, tr of dxy, then xx-mid, xx-side, yy-mid, yy-side): skimage's _integ, clipping included.
 template <int SIZE, int K, typename ACC>
 __device__ __forceinline__ double hessian_box(const ACC &a, int r, int c)
 {
@@ -138,13 +97,6 @@ __device__ __forceinline__ double hessian_det_pruned(const ACC &a, int r, int c,
         det = __dsub_rn(det, __dmul_rn(0.81, __dmul_rn(dxy, dxy)));
     }
     return det;
-}
-
-// compile-time box size: every corner offset folds into the load instruction's immediate (LDS tiles: one base address per pixel)
-template <int SIZE, typename ACC>
-__device__ __forceinline__ double hessian_det_fixed(const ACC &a, int r, int c)
-{
-    return hessian_det_acc(a, SIZE, r, c);
 }
 
 __device__ __forceinline__ double hessian_det_at(const double *__restrict__ S, int H, int W, int size, int r, int c)

@@ -321,119 +321,8 @@ __device__ __forceinline__ void rt_push_maxima(const RtArgs &a, int ls, int r, i
         }
 }
 
-// ------------------------------------------------------------------------------------------------ K3 (general box sizes): determinants + maxima
-#define RTG_TH 16
-#define RTG_TW 64
-#define RTG_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
-#define RTG_BR (RTG_TH + 2 + 14 + 16)        // 48 rows: offsets -14 .. +16 around the 18 determinant rows
-#define RTG_BC (RTG_TW + 2 + 14 + 16)        // 96 columns
-#define RTG_DET_THREADS 256
-// persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
-// with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
-#define RT_DET_GRID 4093
-#ifndef RTG_DET_LDS
-#define RTG_DET_LDS 1
-#endif
-__global__ __launch_bounds__(RTG_DET_THREADS) void rt_det_mask_general_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
-{
-    __shared__ double det[2][RTG_TH + 2][RTG_TW + 2];
-#if RTG_DET_LDS
-    __shared__ double sblk[RTG_BR * RTG_BC];
-#endif
-    // persistent-style grid: the number of live slots is known only on the device, and two million empty workgroups per
-    // chunk cost more to dispatch than the whole tracking step
-    const int nact = min(P, max(0, *a.rt_n - first));
-    const int per = tiles_x * tiles_y;
-    for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
-    const int ls = work / per, trem = work - ls * per;
-    const int W = a.W, H = a.W;
-    const double *S = a.S + (int64_t)ls * W * W;
-    const int r0 = (trem / tiles_x) * RTG_TH, c0 = (trem % tiles_x) * RTG_TW, t = threadIdx.x;
-    __syncthreads();
-    // the 18 x 66 determinants of a tile read the integral image at rows r0-15 .. r0+32 and columns c0-15 .. c0+80 (box size
-    // 30: offsets -14 .. +16).  Staging that 48 x 96 block in LDS was measured and rejected: 150 us per detection at 2 and at 4
-    // waves per SIMD against 142 us for L1 reads at full occupancy
-    const bool interior = r0 >= RTG_HALO && r0 - RTG_HALO + RTG_BR <= H && c0 >= RTG_HALO && c0 - RTG_HALO + RTG_BC <= W && a.size1 == 15 && a.size2 == 30;
-    // outside the image the 3x3x3 footprint sees nothing that could exceed v (mode = 'constant', 0 < threshold < v)
-#if RTG_DET_LDS
-    if (a.size1 == 15 && a.size2 == 30) {
-        // stage the 48 x 96 block of the integral image once (source indices clipped at the image border: a clipped corner index
-        // never leaves rows r0-15 .. r0+32 / columns c0-15 .. c0+80); then every thread walks its positions with the corner loads
-        // of the NEXT determinant in flight while the arithmetic of the current one runs (layer 15, layer 30, layer 15, ...)
-        for (int i = t; i < RTG_BR * RTG_BC; i += RTG_DET_THREADS) {
-            const int rr = i / RTG_BC, cc = i - rr * RTG_BC;
-            sblk[i] = interior ? S[(int64_t)(r0 - RTG_HALO + rr) * W + (c0 - RTG_HALO + cc)]
-                               : S[(int64_t)clipi(r0 - RTG_HALO + rr, 0, H - 1) * W + clipi(c0 - RTG_HALO + cc, 0, W - 1)];
-        }
-        __syncthreads();
-        constexpr int NPOS = (RTG_TH + 2) * (RTG_TW + 2);
-        auto sweep = [&](const auto &acc) {
-            int rr = t / (RTG_TW + 2), cc = t - rr * (RTG_TW + 2);
-            double va[32], vb[32];
-            if (t < NPOS) hessian_corners<15>(acc, r0 + rr - 1, c0 + cc - 1, va);
-            for (int i = t; i < NPOS; i += RTG_DET_THREADS) {
-                const int r = r0 + rr - 1, c = c0 + cc - 1;
-                hessian_corners<30>(acc, r, c, vb);
-                double d0 = hessian_from_corners<15>(va);
-                int nr = rr + RTG_DET_THREADS / (RTG_TW + 2), nc = cc + RTG_DET_THREADS % (RTG_TW + 2);
-                if (nc >= RTG_TW + 2) { nc -= RTG_TW + 2; nr++; }
-                if (i + RTG_DET_THREADS < NPOS) hessian_corners<15>(acc, r0 + nr - 1, c0 + nc - 1, va);
-                double d1 = hessian_from_corners<30>(vb);
-                if (r < 0 || r >= H || c < 0 || c >= W) { d0 = 0.0; d1 = 0.0; }     // outside the image: nothing that could exceed a maximum
-                det[0][rr][cc] = d0; det[1][rr][cc] = d1;
-                rr = nr; cc = nc;
-            }
-        };
-        if (interior) sweep(DohLdsAcc<RTG_BC>{sblk, r0 - RTG_HALO, c0 - RTG_HALO});
-        else sweep(DohLdsClipAcc<RTG_BC>{sblk, r0 - RTG_HALO, c0 - RTG_HALO, H, W});
-    } else
-#endif
-    {
-        // general box sizes (not used by the engine's fixed parameters): 2 x 18 x 66 = 2376 (layer, row, column) items
-        constexpr int NPOS = (RTG_TH + 2) * (RTG_TW + 2);
-        int l = t / NPOS, rem = t - l * NPOS;
-        int rr = rem / (RTG_TW + 2), cc = rem - rr * (RTG_TW + 2);
-        for (int i = t; i < 2 * NPOS; i += RTG_DET_THREADS) {
-            const int r = r0 + rr - 1, c = c0 + cc - 1;
-            double v = 0.0;
-            if (r >= 0 && r < H && c >= 0 && c < W) {
-#if !RTG_DET_LDS
-                if (a.size1 == 15 && a.size2 == 30) {
-                    if (interior) { const DohGlobalInteriorAcc ga = {S, W}; v = l == 0 ? hessian_det_fixed<15>(ga, r, c) : hessian_det_fixed<30>(ga, r, c); }
-                    else { const DohGlobalAcc gc = {S, H, W}; v = l == 0 ? hessian_det_fixed<15>(gc, r, c) : hessian_det_fixed<30>(gc, r, c); }
-                } else
-#endif
-                v = hessian_det_at(S, H, W, l == 0 ? a.size1 : a.size2, r, c);
-            }
-            det[l][rr][cc] = v;
-            rr += RTG_DET_THREADS / (RTG_TW + 2); cc += RTG_DET_THREADS % (RTG_TW + 2);
-            if (cc >= RTG_TW + 2) { cc -= RTG_TW + 2; rr++; }
-            if (rr >= RTG_TH + 2) { rr -= RTG_TH + 2; l++; }
-        }
-    }
-    __syncthreads();
-    const int cc = t & 63, rb = t >> 6;
-    for (int k = 0; k < RTG_TH / (RTG_DET_THREADS / 64); k++) {
-        const int rr = rb * (RTG_TH / (RTG_DET_THREADS / 64)) + k, r = r0 + rr, c = c0 + cc;
-        if (r >= H || c >= W) continue;
-        // 3x3x3 footprint = the 18 determinants around the pixel in both layers: one maximum, loaded without branches
-        // (a short-circuit chain of 36 dependent LDS reads per pixel was 3/4 of this kernel's time)
-        double m = det[0][rr][cc];
-#pragma unroll
-        for (int ll = 0; ll < 2; ll++)
-#pragma unroll
-            for (int dr = 0; dr < 3; dr++)
-#pragma unroll
-                for (int dc = 0; dc < 3; dc++) { const double u = det[ll][rr + dr][cc + dc]; m = u > m ? u : m; }
-        const double v0 = det[0][rr + 1][cc + 1], v1 = det[1][rr + 1][cc + 1];
-        const uint32_t bits = ((v0 > a.threshold && !(m > v0)) ? 1u : 0u) | ((v1 > a.threshold && !(m > v1)) ? 2u : 0u);
-        if (bits) rt_push_maxima(a, ls, r, c, bits, v0, v1);
-    }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ K3: determinants + maxima
-// The engine's box sizes (15, 30).  A workgroup of 8 waves owns a 30 x 62 pixel tile: with the one-pixel halo of the 3x3x3 maxima
+// Box sizes (15, 30) = int(3 sigma) of the engine's detector parameters, compile-time.  A workgroup of 8 waves owns a 30 x 62 pixel tile: with the one-pixel halo of the 3x3x3 maxima
 // that is a 32 x 64 grid of determinant positions (wave = row, lane = column, four rows per wave), which read the integral image at
 // rows r0-15 .. r0+46 and columns c0-15 .. c0+78 (box size 30: offsets -14 .. +16): that 62 x 94 block is staged in LDS once.
 // Determinants come from hessian_det_pruned (doh_common.h): a position whose dxx*dyy does not exceed the threshold skips the dxy
@@ -823,12 +712,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B)
         {
             const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
             const int64_t all = (int64_t)tx * ty * P;
-            if (a.size1 == 15 && a.size2 == 30)
-                hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
-            else {
-                const int gx = (W + RTG_TW - 1) / RTG_TW, gy = (W + RTG_TH - 1) / RTG_TH;
-                hipLaunchKernelGGL(rt_det_mask_general_kernel, dim3((unsigned)std::min<int64_t>((int64_t)P * gx * gy, RT_DET_GRID)), dim3(RTG_DET_THREADS), 0, st, a, first, P, gx, gy);
-            }
+            if (a.size1 != 15 || a.size2 != 30) return hipErrorInvalidValue;      // the engine's fixed detector parameters (box sizes are compile-time)
+            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
         }
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);

@@ -88,6 +88,45 @@ def test_engine_device_retrack_matches_oracle():
     ctx.close()
 
 
+def test_large_chunk_takes_the_one_sweep_integral_kernel():
+    """chunks of >= 200 detections use rt_integral_kernel (one sweep, image written once), smaller ones the two-pass kernels
+    (retrack.hip: rt_one_sweep): 224 lanes on three distinct sequences all run out of features in the same step; every lane
+    must end with the oracle's features for its sequence, bit for bit - and so must the same lanes through 2-detection chunks"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    seqs = [synth.make_sequence(31 + k, 2, n_movers=6, distortion=True) for k in range(3)]
+    B = 224
+    ctx = _ffi.Context(0)
+    want = []
+    for recs, poses, feat in seqs:
+        pipe = oracle.OdometryPipeline(recs[0], feat[:24], poses[0], detect=_detect)
+        w = pipe.step(recs[1])
+        assert w["retrack"]
+        want.append((w, pipe.blobCoord.copy()))
+    for slots, lanes in ((B, B), (2, 6)):
+        eng = Engine(lanes, 2 * lanes, ctx=ctx, retrack_on_device=True, retrack_slots=slots)
+        for k, (recs, poses, feat) in enumerate(seqs):
+            for t in range(2):
+                eng.upload_scan(2 * k + t, recs[t])
+        for b in range(3, lanes):
+            for t in range(2):
+                eng.copy_scan(2 * b + t, 2 * (b % 3) + t)
+        eng.synchronize()
+        for b in range(lanes):
+            recs, poses, feat = seqs[b % 3]
+            eng.init_lane(b, 2 * b, feat[:24], poses[0])
+        eng.step(np.arange(lanes, dtype=np.int32) * 2 + 1)
+        res = eng.results()
+        for b in range(lanes):
+            w, blobs = want[b % 3]
+            assert res[b]["retracked_on_device"] and res[b]["detect_overflow"] == 0, (slots, b)
+            assert res[b]["n_after_retrack"] == len(blobs), (slots, b)
+            assert np.array_equal(eng.lane_features(b), blobs), (slots, b)
+            _same_pose(res[b], w, (slots, b))
+        eng.close()
+    ctx.close()
+
+
 def test_device_retrack_on_the_reference_real_scans():
     """the reference's 11 real data/tiny scans through a 1-lane engine with device-side detection and retracks (features
     collapse from ~200 to < 60 within two or three real frames) vs the oracle's loop body, every step"""
