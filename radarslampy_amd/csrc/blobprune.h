@@ -111,6 +111,47 @@ BP_HDN void bp_nth_element(IDX *idx, int first, int nth, int last, const int16_t
 // ------------------------------------------------------------------------------------------------ cKDTree build
 // xy: n x 2 int16 [row, col]; idx: n (filled 0..n-1 here); returns the node count or -1 on overflow.
 // stack: caller-provided scratch of 3 * 64 ints; node_cap: capacity of nodes (BP_MAX_NODES in LDS on the device).
+// one node of the build: bounds, split dimension, median split with scipy's partition passes.  Returns the first index of the
+// "greater" half (the node is split into [start, p) and [p, end)) or -1 for a leaf; nd receives split_dim / split.
+template <typename IDX>
+BP_HDN int bp_build_node(const int16_t *xy, IDX *idx, int start, int end, BpNode &nd)
+{
+    nd.start = (int16_t)start; nd.end = (int16_t)end; nd.less = nd.greater = -1; nd.split_dim = -1; nd.split = 0;
+    if (end - start <= BP_LEAF) return -1;
+    int mx0 = xy[2 * idx[start]], mn0 = mx0, mx1 = xy[2 * idx[start] + 1], mn1 = mx1;   // compact_nodes bounds
+    for (int j = start + 1; j < end; j++) {
+        const int v0 = xy[2 * idx[j]], v1 = xy[2 * idx[j] + 1];
+        mx0 = v0 > mx0 ? v0 : mx0; mn0 = v0 < mn0 ? v0 : mn0;
+        mx1 = v1 > mx1 ? v1 : mx1; mn1 = v1 < mn1 ? v1 : mn1;
+    }
+    int d = 0, size = 0;
+    if (mx0 - mn0 > size) { d = 0; size = mx0 - mn0; }
+    if (mx1 - mn1 > size) { d = 1; size = mx1 - mn1; }
+    if (size <= 0) return -1;
+    const int i = (end - start) / 2;
+    bp_nth_element(idx, start, start + i, end, xy, d);
+    int split = BP_KEY(idx[start + i]);
+    int p = start, q = end - 1;
+    while (p <= q) {
+        if (BP_KEY(idx[p]) < split) p++;
+        else if (BP_KEY(idx[q]) >= split) q--;
+        else { IDX t = idx[p]; idx[p] = idx[q]; idx[q] = t; p++; q--; }
+    }
+    if (p == start) {                           // no point below the split: slide to the smallest
+        int j = start; split = BP_KEY(idx[j]);
+        for (int k = start + 1; k < end; k++) if (BP_KEY(idx[k]) < split) { j = k; split = BP_KEY(idx[j]); }
+        IDX t = idx[start]; idx[start] = idx[j]; idx[j] = t;
+        p = start + 1;
+    } else if (p == end) {
+        int j = end - 1; split = BP_KEY(idx[j]);
+        for (int k = start; k < end - 1; k++) if (BP_KEY(idx[k]) > split) { j = k; split = BP_KEY(idx[j]); }
+        IDX t = idx[end - 1]; idx[end - 1] = idx[j]; idx[j] = t;
+        p = end - 1;
+    }
+    nd.split_dim = (int16_t)d; nd.split = split;
+    return p;
+}
+
 template <typename IDX>
 BP_HDN int bp_build(const int16_t *xy, int n, IDX *idx, BpNode *nodes, int node_cap, int *stack)
 {
@@ -124,43 +165,11 @@ BP_HDN int bp_build(const int16_t *xy, int n, IDX *idx, BpNode *nodes, int node_
         const int me = nn++;
         if (link >= 0) { if (link & 1) nodes[link >> 1].greater = (int16_t)me; else nodes[link >> 1].less = (int16_t)me; }
         BpNode nd;
-        nd.start = (int16_t)start; nd.end = (int16_t)end; nd.less = nd.greater = -1; nd.split_dim = -1; nd.split = 0;
-        if (end - start > BP_LEAF) {
-            int mx0 = xy[2 * idx[start]], mn0 = mx0, mx1 = xy[2 * idx[start] + 1], mn1 = mx1;   // compact_nodes bounds
-            for (int j = start + 1; j < end; j++) {
-                const int v0 = xy[2 * idx[j]], v1 = xy[2 * idx[j] + 1];
-                mx0 = v0 > mx0 ? v0 : mx0; mn0 = v0 < mn0 ? v0 : mn0;
-                mx1 = v1 > mx1 ? v1 : mx1; mn1 = v1 < mn1 ? v1 : mn1;
-            }
-            int d = 0, size = 0;
-            if (mx0 - mn0 > size) { d = 0; size = mx0 - mn0; }
-            if (mx1 - mn1 > size) { d = 1; size = mx1 - mn1; }
-            if (size > 0) {
-                const int i = (end - start) / 2;
-                bp_nth_element(idx, start, start + i, end, xy, d);
-                int split = BP_KEY(idx[start + i]);
-                int p = start, q = end - 1;
-                while (p <= q) {
-                    if (BP_KEY(idx[p]) < split) p++;
-                    else if (BP_KEY(idx[q]) >= split) q--;
-                    else { IDX t = idx[p]; idx[p] = idx[q]; idx[q] = t; p++; q--; }
-                }
-                if (p == start) {                           // no point below the split: slide to the smallest
-                    int j = start; split = BP_KEY(idx[j]);
-                    for (int k = start + 1; k < end; k++) if (BP_KEY(idx[k]) < split) { j = k; split = BP_KEY(idx[j]); }
-                    IDX t = idx[start]; idx[start] = idx[j]; idx[j] = t;
-                    p = start + 1;
-                } else if (p == end) {
-                    int j = end - 1; split = BP_KEY(idx[j]);
-                    for (int k = start; k < end - 1; k++) if (BP_KEY(idx[k]) > split) { j = k; split = BP_KEY(idx[j]); }
-                    IDX t = idx[end - 1]; idx[end - 1] = idx[j]; idx[j] = t;
-                    p = end - 1;
-                }
-                nd.split_dim = (int16_t)d; nd.split = split;
-                if (sp + 2 > 64) return -1;
-                stack[3 * sp] = p; stack[3 * sp + 1] = end; stack[3 * sp + 2] = 2 * me + 1; sp++;     // greater: built after
-                stack[3 * sp] = start; stack[3 * sp + 1] = p; stack[3 * sp + 2] = 2 * me; sp++;       // the whole less subtree
-            }
+        const int p = bp_build_node(xy, idx, start, end, nd);
+        if (p >= 0) {
+            if (sp + 2 > 64) return -1;
+            stack[3 * sp] = p; stack[3 * sp + 1] = end; stack[3 * sp + 2] = 2 * me + 1; sp++;     // greater: built after
+            stack[3 * sp] = start; stack[3 * sp + 1] = p; stack[3 * sp + 2] = 2 * me; sp++;       // the whole less subtree
         }
         nodes[me] = nd;
     }

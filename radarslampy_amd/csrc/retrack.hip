@@ -496,10 +496,46 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         L.xy[2 * rank] = (int16_t)(p >> 16); L.xy[2 * rank + 1] = (int16_t)((p >> 2) & 0x3fff); L.lay[rank] = (uint8_t)(p & 3);
     }
     __syncthreads();
-    // 2. cKDTree + dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
+    // 2. cKDTree, level by level: every node of a level is built by its own lane (bounds, libstdc++ nth_element, scipy's
+    // partition passes - sequential per node, but a level's nodes work on disjoint index ranges), so the critical path is the
+    // largest node of every level (~2 n element visits) instead of all of them (~n log n: the build on lane 0 was 1.6 of this
+    // kernel's 3.2 ms).  Nodes are numbered level by level; nothing downstream depends on the numbering, only on the links.
+    for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)i;
+    int nn = 0;
+    if (n > 0) {
+        if (lane == 0) { L.nodes[0].start = 0; L.nodes[0].end = (int16_t)n; }
+        nn = 1;
+        __syncthreads();
+        for (int lo = 0, hi = 1; lo < hi && nn > 0;) {
+            for (int base = lo; base < hi; base += 64) {
+                const int me = base + lane;
+                const bool act = me < hi;
+                BpNode nd;
+                int p = -1, start = 0, end = 0;
+                if (act) { start = L.nodes[me].start; end = L.nodes[me].end; p = bp_build_node(L.xy, L.idx, start, end, nd); }
+                const uint64_t bal = __ballot(act && p >= 0);
+                const int kids = 2 * __popcll(bal);
+                if (nn + kids > BP_MAX_NODES) { nn = -1; break; }              // (uniform)
+                if (act) {
+                    if (p >= 0) {
+                        const int c0 = nn + 2 * __popcll(bal & ((1ull << lane) - 1ull));
+                        nd.less = (int16_t)c0; nd.greater = (int16_t)(c0 + 1);
+                        L.nodes[c0].start = (int16_t)start; L.nodes[c0].end = (int16_t)p;
+                        L.nodes[c0 + 1].start = (int16_t)p; L.nodes[c0 + 1].end = (int16_t)end;
+                    }
+                    L.nodes[me] = nd;
+                }
+                nn += kids;
+            }
+            if (nn < 0) break;
+            __syncthreads();
+            lo = hi; hi = nn;
+        }
+    }
+    __syncthreads();
+    // dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
     BpTask *tasks = a.tasks + (int64_t)ls * BP_MAX_TASKS;
     if (lane == 0) {
-        int nn = n > 0 ? bp_build(L.xy, n, L.idx, L.nodes, BP_MAX_NODES, L.bstack) : 0;
         int nt = 0;
         if (nn < 0) flags |= RT_F_TREE_OVERFLOW;
         else if (n > 1) {
