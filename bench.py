@@ -141,7 +141,20 @@ def run_rank(args):
         from radarslampy_amd.engine import Engine
         ctx = _ffi.Context(local_rank)
         info = ctx.device_info()
-        comm = D.RcclComm(ctx, rdv) if rdv else None
+        comm = None
+        if rdv:
+            # native RCCL communicator (csrc/comm.hip).  If it cannot be created on ANY rank (no librccl, IPC refused ...) every
+            # rank agrees - through the rendezvous directory - to aggregate the timing through files instead, so that a line is
+            # still printed; "collective_backend" says which one ran
+            try:
+                comm = D.RcclComm(ctx, rdv)
+            except Exception as ex:                                     # noqa: BLE001
+                sys.stderr.write(f"[bench] rank {rank}: RCCL communicator failed ({ex}); falling back to the file communicator\n")
+            votes = rdv.gather("rccl_ok", b"1" if comm is not None else b"0")
+            if any(v != b"1" for v in votes):
+                if comm is not None:
+                    comm.close_native()
+                comm = D.FileComm(rdv)
         E = max(1, args.engines)
         assert B % E == 0
         BE = B // E

@@ -6,6 +6,7 @@
 // fails with ROAM_E_STATE and a message when it is missing.
 #include "roam_internal.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 struct RcclApi {
@@ -27,6 +28,7 @@ static RcclApi *rccl_api()
     static bool tried = false;
     if (tried) return &api;
     tried = true;
+    if (getenv("ROAM_DISABLE_RCCL")) { snprintf(api.why, sizeof(api.why), "disabled by ROAM_DISABLE_RCCL"); return &api; }   // (exercises callers' fallbacks)
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char *n : names) {
         api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);

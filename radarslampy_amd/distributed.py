@@ -7,7 +7,8 @@ csrc/comm.hip) - no torch, no host bounce of the payload on the sending side.
 
 Rendezvous (who am I, where is the ncclUniqueId) is a directory on the node's local file system: rank 0 writes the
 128-byte id, the others read it.  `FileComm` offers the same interface on files only; it exists for `bench.py
---dry-engine`, the CPU test of the launcher, and is never used on a GPU run."""
+--dry-engine`, the CPU test of the launcher, and as bench.py's agreed fallback when RCCL cannot be initialised on some rank
+(the JSON line then says "collective_backend": "file")."""
 import json
 import os
 import time
@@ -146,10 +147,12 @@ class RcclComm:
             ident = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
             rc = ctx.lib.roam_comm_unique_id(ident)
             if rc != _ffi.ROAM_OK:
+                rdv.put("rccl_id", b"")                          # the other ranks fail at once instead of waiting for an id
                 raise _ffi.RoamError(rc, "roam_comm_unique_id failed (librccl.so missing?)")
             rdv.put("rccl_id", bytes(ident))
         raw = rdv.get("rccl_id", 0)
-        assert len(raw) == _ffi.COMM_ID_BYTES
+        if len(raw) != _ffi.COMM_ID_BYTES:
+            raise _ffi.RoamError(_ffi.ROAM_E_STATE, "rank 0 could not create an RCCL unique id")
         ident = (C.c_uint8 * _ffi.COMM_ID_BYTES).from_buffer_copy(raw)
         with _stdout_to_stderr():
             ctx.check(ctx.lib.roam_comm_init(ctx.h, ident, self.rank, self.world))
@@ -180,6 +183,10 @@ class RcclComm:
                                                         _ffi._ptr(pk), cap))
         return dict(pose=np.array(hdr.pose[:]), velocity=np.array(hdr.velocity[:]),
                     prunedUndistortedLocals=loc[:hdr.n_features].copy(), peaks=pk[:hdr.n_peaks].copy(), scan=hdr.scan, lane=hdr.lane)
+
+    def close_native(self):
+        """drop the communicator only (the rendezvous stays: bench.py's fallback to FileComm)"""
+        self.ctx.lib.roam_comm_destroy(self.ctx.h)
 
     def close(self):
         self.barrier()
