@@ -165,7 +165,9 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #define RI_WAVES 4
 #define RI_GROUPS (2048 / (64 * RI_WAVES))
 #define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8)
-struct __attribute__((packed)) RtU16 { uint16_t v; };                      // two neighbouring codes in one (unaligned) load
+struct __attribute__((packed)) RtU16 { uint16_t v; };
+struct __attribute__((packed)) RtU32 { uint32_t v; };
+#define RI_BOX 1536                        // bytes of polar footprint a column wave may stage (rt_integral_kernel)                      // two neighbouring codes in one (unaligned) load
 __device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict__ p, int rows, int cols, int stride, const float *lut)
 {
     const int ix = m & 4095, iy = (m >> 12) & 1023;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
     const int W = a.W, H = a.W, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int nbands = (H + RI_ROWS - 1) / RI_ROWS;
     __shared__ float lut[256];
+    __shared__ __align__(4) uint8_t box[RI_WAVES][RI_BOX];
     if (t < 256) lut[t] = rt_code_to_f32(t);
     __syncthreads();
     if (wave < RI_WAVES) {
@@ -219,8 +222,67 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
             Tile &tl = tiles[((band * RI_GROUPS + g) & 1) * RI_WAVES + wave];
             float v[RI_ROWS];
+            // The polar footprint of the wave's 64 x 16 pixel patch is a small box (range span x azimuth span, a few hundred bytes):
+            // it is copied into LDS with a handful of coalesced row loads (16 lanes per polar row, four rows per instruction) and
+            // the 4 taps per pixel become LDS byte reads; per-lane byte gathers from global memory (two 16-bit loads per pixel,
+            // 32 wave-level gathers per phase) kept the texture addresser busy for 8 of this kernel's 19 us.  Patches whose box
+            // does not fit (next to the image centre, across the 0 / 2 pi seam) gather as before.
+            int mnx = 0x7fffffff, mxx = -1, mny = 0x7fffffff, mxy = -1;
 #pragma unroll
-            for (int k = 0; k < RI_ROWS; k++) v[k] = rt_pixel(m[k], p, rows, cols, stride, lut);
+            for (int k = 0; k < RI_ROWS; k++) {
+                const int ix = m[k] & 4095, iy = (m[k] >> 12) & 1023;
+                if (ix < cols) { mnx = min(mnx, ix); mxx = max(mxx, ix); mny = min(mny, iy); mxy = max(mxy, iy); }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
+                mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
+            }
+            mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);
+            mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
+            const int bw = mxx - mnx + 2, bh = mxy - mny + 2, bp = (bw + 3) & ~3;
+            if (mxx < 0) {
+#pragma unroll
+                for (int k = 0; k < RI_ROWS; k++) v[k] = 0.f;              // beyond the maximum range
+            } else if (bp * bh <= RI_BOX) {
+                uint8_t *bx = box[wave];
+                const int sub = lane >> 4, c4 = (lane & 15) * 4;
+                for (int kg = 0; kg < bh; kg += 4) {
+                    const int kk = kg + sub;
+                    int r = mny + kk - 1;
+                    if (r < 0) r += rows; else if (r >= rows) r -= rows;
+                    for (int cb = 0; cb < bp; cb += 64) {
+                        const int cc = cb + c4;
+                        if (kk < bh && cc < bp) {
+                            // bytes beyond the scan's last range bin read as zero: the load is moved back inside the row and shifted
+                            const int x0 = mnx + cc, xl = min(x0, cols - 4), sh = 8 * (x0 - xl);
+                            uint32_t raw = 0;
+                            if (sh < 32) raw = reinterpret_cast<const RtU32 *>(p + r * stride + xl)->v >> sh;
+                            *reinterpret_cast<uint32_t *>(bx + kk * bp + cc) = raw;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < RI_ROWS; k++) {
+                    const uint32_t mk = m[k];
+                    const int ix = mk & 4095, iy = (mk >> 12) & 1023;
+                    float r_ = 0.f;
+                    if (ix < cols) {
+                        const float wx1 = __fmul_rn((float)((mk >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+                        const float wy1 = __fmul_rn((float)(mk >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+                        const uint8_t *q = bx + (iy - mny) * bp + (ix - mnx);
+                        const float s00 = lut[q[0]], s01 = lut[q[1]], s10 = lut[q[bp]], s11 = lut[q[bp + 1]];   // lut[0] = 0: bins past the scan
+                        r_ = __fmul_rn(s00, __fmul_rn(wy0, wx0));
+                        r_ = __fadd_rn(r_, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
+                        r_ = __fadd_rn(r_, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
+                        r_ = __fadd_rn(r_, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
+                    }
+                    v[k] = r_;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RI_ROWS; k++) v[k] = rt_pixel(m[k], p, rows, cols, stride, lut);
+            }
             // the next phase's map words leave now; they land while the row wave works
             if (g + 1 < RI_GROUPS) fetch(band, g + 1); else if (band + 1 < nbands) fetch(band + 1, 0);
             if (c < W) {
