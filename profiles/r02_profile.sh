@@ -8,6 +8,7 @@ python bench.py > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --cpu-pairs 0 > $O/bench_profiled.json 2> $O/prof.log
 cp $O/prof/*/*kernel_stats.csv $O/kernel_stats.csv
 python3 profiles/trace_summary.py $O/prof > $O/trace_summary.csv 2>/dev/null
+rm -f $O/prof/*/*kernel_trace.csv          # tens of MB; the summary above is what gets committed
 OUT=$O/pmc; mkdir -p $OUT
 # PMC serialises every dispatch: at 4096 lanes the 70 000 dispatches of the lane set-up alone take longer than a GPU slot lasts (rocprofv3 aborted);
 # the detection kernels work on `retrack_slots` = 512 detections per launch whatever the lane count, so 512 lanes measure the same launches
