@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             if (mxx < 0) {
 #pragma unroll
                 for (int k = 0; k < RI_ROWS; k++) v[k] = 0.f;              // beyond the maximum range
-            } else if (bp * bh <= RI_BOX) {
+            } else if (bp * bh <= RI_BOX && cols >= 4) {
                 uint8_t *bx = box[wave];
                 const int sub = lane >> 4, c4 = (lane & 15) * 4;
                 for (int kg = 0; kg < bh; kg += 4) {
