@@ -127,6 +127,72 @@ def test_large_chunk_takes_the_one_sweep_integral_kernel():
     ctx.close()
 
 
+def test_detection_overflow_is_flagged_not_fatal():
+    """a scan of white noise has far more determinant maxima than the 2048 candidates a detection keeps: the lane's result
+    carries the overflow bits (roam_abi.h: flags bits 8..11), nothing hangs or faults, the lane keeps a usable feature set and
+    a well-behaved neighbour lane in the same chunk is not disturbed"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(41, 3, n_movers=4)
+    rng = np.random.default_rng(7)
+    noise = [r.copy() for r in recs]
+    for r in noise:
+        r[:, 11:] = rng.integers(0, 256, size=r[:, 11:].shape, dtype=np.uint8)
+    ctx = _ffi.Context(0)
+    eng = Engine(2, 6, ctx=ctx, retrack_on_device=True)
+    for t in range(3):
+        eng.upload_scan(t, noise[t])
+        eng.upload_scan(3 + t, recs[t])
+    eng.init_lane_detect(0, 0, poses[0])
+    eng.init_lane_detect(1, 3, poses[0])
+    cart = oracle.convertPolarImageToCartesian(recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.))
+    want1 = oracle.append_dedupe(np.empty((0, 2)), _detect(cart))
+    assert np.array_equal(eng.lane_features(1), want1)
+    f0 = eng.lane_features(0)
+    assert 0 < len(f0) <= 1024 and np.isfinite(f0).all() and (f0 >= 0).all() and (f0 < W).all()
+    eng.set_retrack(2)                                       # both lanes detect again in the step, in one chunk
+    eng.step([1, 4])
+    res = eng.results()
+    assert res[0]["retracked_on_device"] and res[0]["detect_overflow"] != 0
+    assert res[1]["retracked_on_device"] and res[1]["detect_overflow"] == 0
+    eng.set_retrack(1)
+    eng.step([2, 5])
+    res = eng.results()
+    assert np.isfinite(res[0]["pose"]).all() and np.isfinite(res[1]["pose"]).all()
+    eng.close()
+    ctx.close()
+
+
+def test_empty_scan_detects_nothing_and_keeps_running():
+    """an all-zero scan has no maxima at all: the detection appends nothing (no candidates, an empty tree, no pairs), the lane
+    reports zero features step after step and its neighbour is not disturbed"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(43, 3, n_movers=4)
+    dark = [r.copy() for r in recs]
+    for r in dark:
+        r[:, 11:] = 0
+    ctx = _ffi.Context(0)
+    eng = Engine(2, 6, ctx=ctx, retrack_on_device=True)
+    for t in range(3):
+        eng.upload_scan(t, dark[t])
+        eng.upload_scan(3 + t, recs[t])
+    eng.init_lane_detect(0, 0, poses[0])
+    eng.init_lane(1, 3, feat, poses[0])
+    assert len(eng.lane_features(0)) == 0
+    pipe = oracle.OdometryPipeline(recs[0], feat, poses[0], detect=_detect)
+    for t in (1, 2):
+        eng.step([t, 3 + t])
+        res = eng.results()
+        want = pipe.step(recs[t])
+        assert res[0]["n_tracked"] == 0 and res[0]["n_after_retrack"] == 0 and res[0]["detect_overflow"] == 0, t
+        assert np.isfinite(res[0]["pose"]).all()
+        assert res[1]["n_inliers"] == want["n_inliers"], t
+        _same_pose(res[1], want, t)
+    eng.close()
+    ctx.close()
+
+
 def test_device_retrack_on_the_reference_real_scans():
     """the reference's 11 real data/tiny scans through a 1-lane engine with device-side detection and retracks (features
     collapse from ~200 to < 60 within two or three real frames) vs the oracle's loop body, every step"""
