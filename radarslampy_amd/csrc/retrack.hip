@@ -438,22 +438,44 @@ __global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a
             }
         }
     };
+    // the maxima of a tile are looked for one iteration later, between the two barriers of the next tile's staging (every thread
+    // has written its per-position maxima by then, nobody overwrites them before the second barrier): two barriers per tile
+    double d0[4], d1[4];
+    int pls = -1, pr0 = 0, pc0 = 0;                                        // the tile whose maxima are pending
+    auto maxima = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = k * 8 + wave, r = pr0 - 1 + rr, c = pc0 - 1 + lane;
+            if (rr < 1 || rr > RT_TH || lane < 1 || lane > RT_TW || r >= H || c >= W) continue;
+            uint32_t bits = 0;
+            if (d0[k] > thr || d1[k] > thr) {
+                // 3x3x3 footprint = the 9 per-position maxima around the pixel (the pixel's own included)
+                double m = m2[rr][lane];
+#pragma unroll
+                for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+                    for (int dc = -1; dc <= 1; dc++) { const double u = m2[rr + dr][lane + dc]; m = u > m ? u : m; }
+                bits = ((d0[k] > thr && !(m > d0[k])) ? 1u : 0u) | ((d1[k] > thr && !(m > d1[k])) ? 2u : 0u);
+            }
+            if (bits) rt_push_maxima(a, pls, r, c, bits, d0[k], d1[k]);
+        }
+    };
     if ((int)blockIdx.x < nact * per) fetch(blockIdx.x);
     for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
         const int ls = work / per, trem = work - ls * per;
         const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW;
         const int rbase = r0 - RT_HALO, cbase = c0 - RT_HALO;
         const bool interior = rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W;
-        __syncthreads();                                                   // the previous tile's readers are done
+        __syncthreads();                                                   // the previous tile's corner reads and maxima writes are done
 #pragma unroll
         for (int qq = 0; qq < 4; qq++)
             if (qq < 3 || srow + 48 < RT_BR) {
 #pragma unroll
                 for (int pp = 0; pp < 3; pp++) sblk[(srow + 16 * qq) * RT_BP + scol + 32 * pp] = stage[qq][pp];
             }
+        if (pls >= 0) maxima();
         __syncthreads();
         if (work + (int)gridDim.x < nact * per) fetch(work + gridDim.x);
-        double d0[4], d1[4];
         if (interior) {
             const DohLdsAcc<RT_BP> acc = {sblk, rbase, cbase};
 #pragma unroll
@@ -477,24 +499,9 @@ __global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a
                 m2[rr][lane] = u1 > u0 ? u1 : u0;
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
-            if (rr < 1 || rr > RT_TH || lane < 1 || lane > RT_TW || r >= H || c >= W) continue;
-            uint32_t bits = 0;
-            if (d0[k] > thr || d1[k] > thr) {
-                // 3x3x3 footprint = the 9 per-position maxima around the pixel (the pixel's own included)
-                double m = m2[rr][lane];
-#pragma unroll
-                for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-                    for (int dc = -1; dc <= 1; dc++) { const double u = m2[rr + dr][lane + dc]; m = u > m ? u : m; }
-                bits = ((d0[k] > thr && !(m > d0[k])) ? 1u : 0u) | ((d1[k] > thr && !(m > d1[k])) ? 2u : 0u);
-            }
-            if (bits) rt_push_maxima(a, ls, r, c, bits, d0[k], d1[k]);
-        }
+        pls = ls; pr0 = r0; pc0 = c0;
     }
+    if (pls >= 0) { __syncthreads(); maxima(); }
 }
 
 // ------------------------------------------------------------------------------------------------ K4: ordered candidates
