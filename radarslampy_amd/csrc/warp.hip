@@ -173,7 +173,7 @@ hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
 }
 
 #ifndef WG_LB
-#define WG_LB 64         // scans of the batch per workgroup (amortises the map read and the weights)
+#define WG_LB 32         // scans of the batch per workgroup (amortises the map read and the weights; 16 / 24 / 48 / 64 / 128 measured slower)
 #endif
 #define WG_TW 64          // tile width  (one wavefront = 64 consecutive pixels of a row)
 #define WG_TH 16          // tile height
