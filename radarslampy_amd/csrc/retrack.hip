@@ -401,7 +401,9 @@ __device__ __forceinline__ void rt_push_maxima(const RtArgs &a, int ls, int r, i
 #define RT_DET_THREADS 512
 // persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
 // with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
+#ifndef RT_DET_GRID
 #define RT_DET_GRID 4093
+#endif
 __global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
 {
     __shared__ double sblk[RT_BR * RT_BP];
