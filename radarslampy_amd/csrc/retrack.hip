@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
     const int c = blockIdx.x * 256 + threadIdx.x, W = a.W;
     if (c >= W) return;
     const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
-    double *S = a.S + (int64_t)ls * W * W;
+    double *S = a.S + (int64_t)ls * a.SP * W;
     const int rows = a.rows, cols = a.cols, stride = a.stride;
     double acc = 0;
     auto pixel = [&](uint32_t m) -> float {              // the arithmetic of warp_gather_kernel's direct path (= warp_pixel)
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = pixel(m[k]);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { acc = __dadd_rn(acc, (double)v[k]); S[(int64_t)(r + k) * W + c] = acc; }
+        for (int k = 0; k < 4; k++) { acc = __dadd_rn(acc, (double)v[k]); S[(int64_t)(r + k) * a.SP + c] = acc; }
     }
-    for (; r < W; r++) { acc = __dadd_rn(acc, (double)pixel(a.map[(int64_t)r * W + c])); S[(int64_t)r * W + c] = acc; }
+    for (; r < W; r++) { acc = __dadd_rn(acc, (double)pixel(a.map[(int64_t)r * W + c])); S[(int64_t)r * a.SP + c] = acc; }
 }
 
 // one wavefront per 64 rows: lane = row, sequential along the row (the reference's summation order); the image streams
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
     const int ls = blockIdx.y, slot = first + ls;
     if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
     const int W = a.W, H = a.W;
-    double *S = a.S + (int64_t)ls * W * W;
+    double *S = a.S + (int64_t)ls * a.SP * W;
     const int lane = threadIdx.x, r0 = blockIdx.x * 64;
     constexpr int RPI = 64 / RT_CW;                     // rows per load instruction
     const int lr = lane / RT_CW, lc = lane % RT_CW;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #pragma unroll 8
         for (int k = 0; k < 64; k += RPI) {
             const int r = r0 + k + lr;
-            tile[k + lr][lc] = (r < H && c < W) ? S[(int64_t)r * W + c] : 0.0;
+            tile[k + lr][lc] = (r < H && c < W) ? S[(int64_t)r * a.SP + c] : 0.0;
         }
         __syncthreads();
         const int nc = min(RT_CW, W - c0);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #pragma unroll 8
         for (int k = 0; k < 64; k += RPI) {
             const int r = r0 + k + lr;
-            if (r < H && c < W) S[(int64_t)r * W + c] = tile[k + lr][lc];
+            if (r < H && c < W) S[(int64_t)r * a.SP + c] = tile[k + lr][lc];
         }
         __syncthreads();
     }
@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
     if (wave < RI_WAVES) {
         // ------------------------------------------------------------------------------------ column waves: C(i-1), A(i+1)
         const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
-        double *S = a.S + (int64_t)ls * W * W;
+        double *S = a.S + (int64_t)ls * a.SP * W;
+        const int SP = a.SP;
         const int rows = a.rows, cols = a.cols, stride = a.stride;
         double acc[RI_GROUPS];                                             // the running sums of this thread's columns
 #pragma unroll
@@ -285,30 +286,34 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             }
             // the next phase's map words leave now; they land while the row wave works
             if (g + 1 < RI_GROUPS) fetch(band, g + 1); else if (band + 1 < nbands) fetch(band + 1, 0);
-            if (c < W) {
-                double s = acc[0];                                         // g is uniform: selects, not indexed registers
+            {
+                // acc[0] is always the running sum of the CURRENT group's column: the groups come round in order, so the array is
+                // rotated by one after every phase (8 register moves; a group-indexed array was kept in scratch memory by the
+                // compiler: 16 MB of extra HBM writes per detection)
+                double s = acc[0];
+                if (c < W) {
 #pragma unroll
-                for (int q = 1; q < RI_GROUPS; q++) s = g == q ? acc[q] : s;
-#pragma unroll
-                for (int k = 0; k < RI_ROWS; k++) {
-                    if (band * RI_ROWS + k < H) s = __dadd_rn(s, (double)v[k]);
-                    tl[k][lane] = s;
+                    for (int k = 0; k < RI_ROWS; k++) {
+                        if (band * RI_ROWS + k < H) s = __dadd_rn(s, (double)v[k]);
+                        tl[k][lane] = s;
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < RI_GROUPS; q++) acc[q] = g == q ? s : acc[q];
+                for (int q = 0; q + 1 < RI_GROUPS; q++) acc[q] = acc[q + 1];
+                acc[RI_GROUPS - 1] = s;
             }
         };
         auto C = [&](int band, int g) {
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
             const Tile &tl = tiles[((band * RI_GROUPS + g) & 1) * RI_WAVES + wave];
             if (c < W) {
-                double *q = S + (int64_t)band * RI_ROWS * W + c;
+                double *q = S + (int64_t)band * RI_ROWS * SP + c;
                 const int nk = min(RI_ROWS, H - band * RI_ROWS);
                 if (nk == RI_ROWS) {
 #pragma unroll
-                    for (int k = 0; k < RI_ROWS; k++) q[(int64_t)k * W] = tl[k][lane];
+                    for (int k = 0; k < RI_ROWS; k++) q[(int64_t)k * SP] = tl[k][lane];
                 } else
-                    for (int k = 0; k < nk; k++) q[(int64_t)k * W] = tl[k][lane];
+                    for (int k = 0; k < nk; k++) q[(int64_t)k * SP] = tl[k][lane];
             }
         };
         fetch(0, 0);
@@ -420,21 +425,22 @@ __global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a
     const int srow = t >> 5, scol = t & 31;
     auto fetch = [&](int work) {
         const int ls = work / per, trem = work - ls * per;
-        const double *S = a.S + (int64_t)ls * W * W;
+        const double *S = a.S + (int64_t)ls * a.SP * W;
+        const int SP = a.SP;
         const int rbase = (trem / tiles_x) * RT_TH - RT_HALO, cbase = (trem % tiles_x) * RT_TW - RT_HALO;
         if (rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W) {
-            const double *q = S + (int64_t)(rbase + srow) * W + cbase + scol;
+            const double *q = S + (int64_t)(rbase + srow) * SP + cbase + scol;
 #pragma unroll
             for (int qq = 0; qq < 4; qq++)
                 if (qq < 3 || srow + 48 < RT_BR) {
-                    stage[qq][0] = q[qq * 16 * W]; stage[qq][1] = q[qq * 16 * W + 32];
-                    if (scol + 64 < RT_BC) stage[qq][2] = q[qq * 16 * W + 64];
+                    stage[qq][0] = q[qq * 16 * SP]; stage[qq][1] = q[qq * 16 * SP + 32];
+                    if (scol + 64 < RT_BC) stage[qq][2] = q[qq * 16 * SP + 64];
                 }
         } else {
             // source indices clipped at the image border: skimage's clipped corner indices never leave the block
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
-                const double *q = S + (int64_t)clipi(rbase + srow + 16 * qq, 0, H - 1) * W;
+                const double *q = S + (int64_t)clipi(rbase + srow + 16 * qq, 0, H - 1) * SP;
 #pragma unroll
                 for (int pp = 0; pp < 3; pp++) stage[qq][pp] = q[clipi(cbase + scol + 32 * pp, 0, W - 1)];
             }
