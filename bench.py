@@ -405,8 +405,9 @@ def roofline(eng, args, B, retrack_fraction):
     detail = {"doh_det_maxima": "float64 box corners out of a 62x94 block of the integral image staged in LDS per 30x62-pixel tile; dxy boxes only where "
                                 "dxx*dyy can pass the threshold (<1 % of the pixels): VALU issue ~49 % and LDS ~47 % busy, HBM fetch 1.4x the algorithmic bytes "
                                 "(halo re-reads that miss L2) - profiles/r02_pmc_det_kernel.txt",
-              "doh_integral": "one sweep, both float64 prefix sums in NumPy's sequential order, image written once: bound by the byte gathers from the polar "
-                              "record (texture addresser ~46 % busy, 8 of its 19 us) and the 1016 dependent phases per detection - profiles/r02_pmc_det_kernel.txt",
+              "doh_integral": "one sweep, both float64 prefix sums in NumPy's sequential order, image written once (HBM writes = the algorithmic 32.8 MB): "
+                              "1016 dependent phases per detection, each waiting on the row loads of a wave's polar footprint and on LDS (VALU 35 %, LDS 33 %, "
+                              "texture addresser 35 % busy) - profiles/r02_pmc_det_kernel.txt",
               "warp_quantise": "VALU / LDS issue (round-1 PMC; two rewrites of the per-scan loop measured slower in round 2, DESIGN.md section 6b)"}.get(dom)
     return {"bound": bound, "bound_detail": detail, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
