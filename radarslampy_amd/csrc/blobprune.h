@@ -38,7 +38,12 @@ struct BpTask { int16_t a, b; int32_t mode; };            // leaf a x leaf b; mo
 
 // ------------------------------------------------------------------------------------------------ nth_element
 // libstdc++ std::nth_element (introselect) on an index array, comparator = coordinate value only (scipy's)
-#define BP_KEY(i) (xy[2 * (int)(i) + d])
+// an element is either an index into xy (host, oracle-sized arrays) or a packed point {row:16, col:16, index:16} whose key needs no
+// second, dependent memory access (device: the sequential selection / partition passes run out of LDS, latency-bound)
+struct BpPt { uint64_t v; };
+BP_HD int bp_key(BpPt e, const int16_t *, int d) { return (int16_t)(e.v >> (16 * d)); }
+template <typename IDX> BP_HD int bp_key(IDX e, const int16_t *xy, int d) { return xy[2 * (int)e + d]; }
+#define BP_KEY(i) bp_key((i), xy, d)
 template <typename IDX>
 BP_HDN void bp_adjust_heap(IDX *f, int hole, int len, IDX value, const int16_t *xy, int d)
 {
@@ -118,9 +123,9 @@ BP_HDN int bp_build_node(const int16_t *xy, IDX *idx, int start, int end, BpNode
 {
     nd.start = (int16_t)start; nd.end = (int16_t)end; nd.less = nd.greater = -1; nd.split_dim = -1; nd.split = 0;
     if (end - start <= BP_LEAF) return -1;
-    int mx0 = xy[2 * idx[start]], mn0 = mx0, mx1 = xy[2 * idx[start] + 1], mn1 = mx1;   // compact_nodes bounds
+    int mx0 = bp_key(idx[start], xy, 0), mn0 = mx0, mx1 = bp_key(idx[start], xy, 1), mn1 = mx1;   // compact_nodes bounds
     for (int j = start + 1; j < end; j++) {
-        const int v0 = xy[2 * idx[j]], v1 = xy[2 * idx[j] + 1];
+        const int v0 = bp_key(idx[j], xy, 0), v1 = bp_key(idx[j], xy, 1);
         mx0 = v0 > mx0 ? v0 : mx0; mn0 = v0 < mn0 ? v0 : mn0;
         mx1 = v1 > mx1 ? v1 : mx1; mn1 = v1 < mn1 ? v1 : mn1;
     }

@@ -546,7 +546,8 @@ struct RtBlobLds {
     int st[3 * 256];
     int bstack[3 * 64];
     BpTracker tr;
-    uint16_t tabA[2048], tabB[8192];
+    uint16_t tabA[2048];
+    alignas(8) uint16_t tabB[8192];   // hash table of the set order; before that the packed points of the tree build (2048 x 8 B)
     uint32_t ovbits[(BP_LDS_PAIRS + 31) / 32 + 1];
     uint32_t pl[RT_PL];               // the pairs, when they fit: the sequential set-order pass reads them one by one
     int vals[8];
@@ -577,7 +578,9 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     // partition passes - sequential per node, but a level's nodes work on disjoint index ranges), so the critical path is the
     // largest node of every level (~2 n element visits) instead of all of them (~n log n: the build on lane 0 was 1.6 of this
     // kernel's 3.2 ms).  Nodes are numbered level by level; nothing downstream depends on the numbering, only on the links.
-    for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)i;
+    BpPt *pt = reinterpret_cast<BpPt *>(L.tabB);          // {row, col, index} per element: keys without a dependent second read
+    for (int i = lane; i < n; i += 64)
+        pt[i].v = (uint64_t)(uint16_t)L.xy[2 * i] | ((uint64_t)(uint16_t)L.xy[2 * i + 1] << 16) | ((uint64_t)i << 32);
     int nn = 0;
     if (n > 0) {
         if (lane == 0) { L.nodes[0].start = 0; L.nodes[0].end = (int16_t)n; }
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
                 const bool act = me < hi;
                 BpNode nd;
                 int p = -1, start = 0, end = 0;
-                if (act) { start = L.nodes[me].start; end = L.nodes[me].end; p = bp_build_node(L.xy, L.idx, start, end, nd); }
+                if (act) { start = L.nodes[me].start; end = L.nodes[me].end; p = bp_build_node(L.xy, pt, start, end, nd); }
                 const uint64_t bal = __ballot(act && p >= 0);
                 const int kids = 2 * __popcll(bal);
                 if (nn + kids > BP_MAX_NODES) { nn = -1; break; }              // (uniform)
@@ -609,6 +612,8 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
             lo = hi; hi = nn;
         }
     }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)(pt[i].v >> 32);          // cKDTree.indices
     __syncthreads();
     // dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
     BpTask *tasks = a.tasks + (int64_t)ls * BP_MAX_TASKS;
