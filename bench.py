@@ -250,7 +250,10 @@ def run_rank(args):
         for en in engs:
             r = en.results_array(step)
             stat["steps"] += 1
-            stat["retracks"] += int(np.count_nonzero(r["flags"] & 8))
+            nrt = int(np.count_nonzero(r["flags"] & 8))
+            stat["retracks"] += nrt
+            if en is engs[0]:
+                stat.setdefault("per_step", {})[step] = nrt           # lanes of engine 0 that re-detected in this step
             stat["overflow"] += int(np.count_nonzero((r["flags"] >> 8) & 15))
             stat["tracked"] += int(r["n_tracked"].sum()); stat["good"] += int(r["n_good"].sum()); stat["inliers"] += int(r["n_inliers"].sum())
 
@@ -268,6 +271,16 @@ def run_rank(args):
     for k in range(max(0, args.steps - 2), args.steps):
         consume(args.warmup + k)
     res = eng.results()
+    # in-step kernel durations of the K timed steps (HIP event pairs recorded by the engine on the kernels' own streams), taken NOW:
+    # the steady / forced segments below enqueue more steps
+    live = None
+    if not args.dry_engine:
+        knames = ["ingest_peaks", "warp_quantise", "pyramid"] + ([] if args.no_retrack else ["doh_integral", "doh_det_maxima"])
+        live = {k: eng.kernel_avg(k, args.steps)[0] for k in knames}
+        if not args.no_retrack:
+            slots_ = min(B // len(engs), args.retrack_slots or 512)
+            per = [min(slots_, stat.get("per_step", {}).get(args.warmup + k, 0)) for k in range(args.steps)]
+            live["doh_units_per_launch"] = float(np.mean(per)) if per else 0.0      # detections in the first chunk of a step, on average
     if comm is not None:
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
 
@@ -343,7 +356,7 @@ def run_rank(args):
             if not extra:
                 out["config"]["stage_ms_last_step"] = {k: round(v, 4) for k, v in eng.stage_times().items()}
             out["config"]["whole_path_Bmin_GBs_per_gpu"] = round(13.07e6 * (value / world) / 1e9, 3)   # SURVEY 8d B_min per steady pair
-            out["roofline"] = roofline(eng, args, B, out["config"].get("retrack_fraction") or 0.0)
+            out["roofline"] = roofline(eng, args, B, out["config"].get("retrack_fraction") or 0.0, live)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, seqs, cyc)
     for en in engs:
@@ -356,15 +369,17 @@ def run_rank(args):
         print(json.dumps(out), flush=True)
 
 
-def roofline(eng, args, B, retrack_fraction):
+def roofline(eng, args, B, retrack_fraction, live_all):
     """roofline of the dominant HBM-streaming kernel of a step.  Candidates: the three front-end kernels (once per lane and
     step) and the two image-scale kernels of the feature re-detection (once per RETRACKING lane: weighted by the observed
-    retrack fraction).  For the front-end kernels `avg_launch_ms` is the average launch duration over the K timed steps
-    from HIP event pairs recorded on the stream the kernel runs on (roam_engine_kernel_avg; nothing synchronises inside the
-    timed region); in the pipelined engine other kernels share the GPU during those launches, so every candidate is also
-    re-launched alone after the timed region (roam_engine_time_kernel, HIP events on its stream) = `isolated_*`."""
+    retrack fraction).  `avg_launch_ms` is the kernel's average launch duration over the K timed steps from HIP event pairs the
+    engine records on the stream the kernel runs on (roam_engine_kernel_avg, read right after the timed region; nothing
+    synchronises inside it) - for a detection kernel the first chunk of every step, whose algorithmic bytes are those of the
+    detections it really held (`units_per_launch`, from the per-step result records).  In the pipelined engine other kernels
+    share the GPU during those launches, so every candidate is also re-launched alone after the timed region
+    (roam_engine_time_kernel, HIP events on its stream) = `isolated_*`."""
     names = ["ingest_peaks", "warp_quantise", "pyramid"]
-    live = {k: eng.kernel_avg(k, args.steps)[0] for k in names}
+    live = {k: v for k, v in live_all.items() if k != "doh_units_per_launch"}
     iso = {k: eng.time_kernel(k, args.kernel_reps) for k in names}
     per_step = {k: iso[k][0] for k in names}                       # ms of the kernel alone per step
     slots = None
@@ -376,9 +391,16 @@ def roofline(eng, args, B, retrack_fraction):
             names.append(k)
     dom = max(per_step, key=per_step.get)
     algo_bytes = iso[dom][1]
-    # in-step duration: measured for the front-end kernels; the detection kernels run inside the retrack stage, whose
-    # launches are spread over chunks - their isolated duration is the one on record
+    units = slots if dom.startswith("doh") else B
+    # in-step duration over the K timed steps.  Front-end kernels: one launch per step over all lanes.  Detection kernels: the
+    # first chunk of every step, which holds min(retrack_slots, lanes that re-detected in that step) detections - the algorithmic
+    # bytes of the live figure are those of the average number of detections per such launch
     ms = live.get(dom, iso[dom][0])
+    if dom.startswith("doh") and live_all.get("doh_units_per_launch", 0) > 0 and ms > 0:
+        units = live_all["doh_units_per_launch"]
+        algo_bytes = iso[dom][1] / slots * units
+    else:
+        ms = live.get(dom, iso[dom][0]) if not dom.startswith("doh") else iso[dom][0]
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     # HBM traffic and VALU instruction counts of that kernel from the PMC passes taken AT THIS LANE COUNT
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.py); null when no pass at this lane count is committed
@@ -400,7 +422,9 @@ def roofline(eng, args, B, retrack_fraction):
                 break
         except Exception:
             continue
-    iso_frac = algo_bytes / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if dom.startswith("doh") and traffic:
+        traffic = int(traffic * units / slots)                  # the PMC pass measured launches of `slots` detections
+    iso_frac = iso[dom][1] / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
     bound = "valu_issue" if (valu_frac is not None and valu_frac > iso_frac) else "hbm"
     detail = {"doh_det_maxima": "float64 box corners out of a 62x94 block of the integral image staged in LDS per 30x62-pixel tile; dxy boxes only where "
                                 "dxx*dyy can pass the threshold (<1 % of the pixels): VALU issue ~49 % and LDS ~47 % busy, HBM fetch 1.4x the algorithmic bytes "
@@ -413,7 +437,7 @@ def roofline(eng, args, B, retrack_fraction):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
             "valu_issue_frac_isolated": None if valu_frac is None else round(valu_frac, 4),
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-            "units_per_launch": slots if dom.startswith("doh") else B,
+            "units_per_launch": round(units, 1),
             "isolated_achieved": round(iso_frac * HBM_PEAK_GBS, 2), "isolated_frac": round(iso_frac, 5),
             "kernel_ms_per_step_alone": {k: round(v, 4) for k, v in per_step.items()},
             "in_step_kernel_ms": {k: round(v, 4) for k, v in live.items()},

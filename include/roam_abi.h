@@ -264,7 +264,10 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
                                 int32_t *n);
 /* average in-step launch time (ms) of a front-end kernel ("ingest_peaks" | "warp_quantise" | "pyramid") over the
  * last `last_steps` steps (<= 64), from HIP event pairs recorded on the stream the kernel runs on; no
- * synchronisation happens inside the steps themselves */
+ * synchronisation happens inside the steps themselves.  "doh_integral" | "doh_det_maxima" (engines with
+ * retrack_on_device): the image-scale kernels of the FIRST detection chunk of each of those steps, i.e. of
+ * min(retrack_slots, lanes that re-detected in the step) detections; n_used counts the steps that had device-side
+ * detection switched on */
 int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_steps, float *avg_ms, int32_t *n_used);
 /* time `reps` launches of the dominant streaming kernel (warp+quantise of all lanes) with
  * HIP events on the context stream; returns average ms per launch. */

@@ -93,6 +93,8 @@ struct Engine {
     // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
     // region without synchronising inside it (roam_engine_kernel_avg)
     hipEvent_t tr_ev[64][6] = {};
+    hipEvent_t rt_ev[64][3] = {};                                      // first detection chunk of a step: integral image | determinants
+    bool rt_ev_ok[64] = {};
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
@@ -443,6 +445,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     kill(e->ev_join); kill(e->ev_pk0); kill(e->ev_pk1); kill(e->ev_warp); kill(e->ev_idx); kill(e->ev_peaks);
     for (int i = 0; i < 4; i++) { kill(e->ev_klt[i]); kill(e->ev_g4[i]); }
     for (auto &row : e->tr_ev) for (auto &ev : row) kill(ev);
+    for (auto &row : e->rt_ev) for (auto &ev : row) kill(ev);
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->results_host) hipHostFree(e->results_host);
     for (auto &ev : e->ev_res) if (ev) hipEventDestroy(ev);
@@ -582,6 +585,10 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     for (auto &row : e->tr_ev)
         for (auto &ev : row)
             if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    if (e->rt_on)
+        for (auto &row : e->rt_ev)
+            for (auto &ev : row)
+                if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     e->tr_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -929,8 +936,9 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
         e->rt.res = res_slot;
         HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->rt_ev[e->nstep & 63]));
     }
+    e->rt_ev_ok[e->nstep & 63] = e->rt_on && e->rt_mode;
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
     HIP_TRY(ctx, hipEventRecord(e->ev_g4[k4], st));
     // per-step result record -> pinned host ring: roam_engine_step_results(step) waits for THIS copy only
@@ -1068,11 +1076,27 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
     ENGINE();
     ARG_CHECK(ctx, name && last_steps >= 1 && avg_ms && n_used);
     int k = !strcmp(name, "ingest_peaks") ? 0 : (!strcmp(name, "warp_quantise") ? 1 : (!strcmp(name, "pyramid") ? 2 : -1));
-    if (k < 0) { ROAM_SET_ERR(ctx, "unknown kernel '%s'", name); return ROAM_E_ARG; }
+    // the two image-scale kernels of the detection: the FIRST chunk of every step (min(retrack_slots, lanes flagged in that step)
+    // detections; steps without device-side detection do not count)
+    const int kd = !strcmp(name, "doh_integral") ? 0 : (!strcmp(name, "doh_det_maxima") ? 1 : -1);
+    if (k < 0 && kd < 0) { ROAM_SET_ERR(ctx, "unknown kernel '%s'", name); return ROAM_E_ARG; }
+    if (kd >= 0 && !e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
     if (!e->stepped) { ROAM_SET_ERR(ctx, "run a step first"); return ROAM_E_STATE; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t n = std::min<int64_t>(std::min<int64_t>(last_steps, e->nstep), 64);
+    int64_t n = std::min<int64_t>(std::min<int64_t>(last_steps, e->nstep), 64);
     double sum = 0;
+    if (kd >= 0) {
+        int64_t used = 0;
+        for (int64_t i = e->nstep - n; i < e->nstep; i++) {
+            if (!e->rt_ev_ok[i & 63]) continue;
+            float ms = 0;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, e->rt_ev[i & 63][kd], e->rt_ev[i & 63][kd + 1]));
+            sum += ms; used++;
+        }
+        *avg_ms = used ? (float)(sum / (double)used) : 0.f;
+        *n_used = (int32_t)used;
+        return ROAM_OK;
+    }
     for (int64_t i = e->nstep - n; i < e->nstep; i++) {
         float ms = 0;
         const int a0 = k == 2 ? 3 : (k == 1 ? 1 : 0), a1 = k == 2 ? 4 : (k == 1 ? 2 : 5);   // peaks and pyramid: their own streams' pairs
