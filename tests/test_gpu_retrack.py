@@ -117,6 +117,9 @@ def test_large_chunk_takes_the_one_sweep_integral_kernel():
             eng.init_lane(b, 2 * b, feat[:24], poses[0])
         eng.step(np.arange(lanes, dtype=np.int32) * 2 + 1)
         res = eng.results()
+        for name in ("doh_integral", "doh_det_maxima"):          # live event pairs around the first detection chunk of the step
+            ms, n = eng.kernel_avg(name, 1)
+            assert n == 1 and 0.0 < ms < 1000.0, (name, ms, n)
         for b in range(lanes):
             w, blobs = want[b % 3]
             assert res[b]["retracked_on_device"] and res[b]["detect_overflow"] == 0, (slots, b)
