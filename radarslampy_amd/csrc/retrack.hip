@@ -1,20 +1,24 @@
 // Device-side feature (re)detection of the engine: appendNewFeatures(currImgCart, good_new) of the reference's loop
 // (RawROAMSystem.py:250-271, getFeatures.py:74-118) for every lane whose step ran out of features, inside
-// roam_engine_step, without a host round trip.  Per flagged lane ("slot"):
-//   K1 rt_integ_cols   float32 Cartesian pixel from the polar record through the engine's sampling map (the arithmetic of
-//                      warp.hip, never written to memory) and the column cumsum of the float64 integral image
-//   K2 rt_integ_rows   row cumsum (sequential order per row, 64 x 64 LDS transpose tiles)
-//   K3 rt_det_mask     box-filter Hessian determinants of both live layers (sigma 5.005 / 10, sizes 15 / 30; the
-//                      sigma 0.01 layer is all-NaN in scikit-image and ignored) on a 16 x 64 tile + halo in LDS, 3x3x3
-//                      maxima above the threshold -> one byte per pixel (bit s = maximum in layer s) + per-row counts
-//   K4 rt_emit         row offsets (scan) and the candidates in C (row, col, layer) order with their responses
-//   K5 rt_blobs        one wavefront per lane: response order, scikit-image's _prune_blobs in ITS pair order (blobprune.h:
-//                      cKDTree emission order + CPython set order; sequential parts on lane 0 out of LDS), NumPy-1.22
-//                      argsort of the sigmas -> keypoints in adaptiveNMS's priority order
-//   K6 ssc_batch       ANMS.ssc (ssc.hip)
-//   K7 rt_append       [x, y] flip, vstack + drop exact duplicates keeping the first (getFeatures.py:109-112), keyframe
-//                      refresh (Mapping.py:59-66 with the frame's velocity), feature count
-// Slots are processed in chunks of `slots` lanes (scratch: 37 MB per slot); every kernel exits at once for slots beyond
+// roam_engine_step, without a host round trip.  Per flagged lane ("slot" = one detection):
+//   K1+K2 rt_integral    the float64 integral image in ONE sweep: float32 Cartesian pixel from the polar record through the engine's
+//                        sampling map (the arithmetic of warp.hip, never written to memory; the polar footprint of a wave's patch
+//                        staged in LDS), column cumsum in registers, row cumsum through double-buffered LDS tiles - both in NumPy's
+//                        sequential order, image written once.  Chunks of fewer than RI_MIN_DETECTIONS detections (and a lane's
+//                        first detection) take rt_integ_cols + rt_integ_rows instead: thousands of threads per detection
+//   K3 rt_det_mask       box-filter Hessian determinants of both live layers (sigma 5.005 / 10, sizes 15 / 30; the sigma 0.01 layer
+//                        is all-NaN in scikit-image and ignored) on 30 x 62 pixel tiles whose 62 x 94 block of the integral image is
+//                        staged in LDS; dxy boxes only where dxx*dyy can pass the threshold; 3x3x3 maxima above the threshold are
+//                        appended to the detection's candidate list
+//   K4 rt_emit           the candidates sorted into C (row, col, layer) order
+//   K5 rt_blobs          one wavefront per lane: response order, scikit-image's _prune_blobs in ITS pair order (blobprune.h:
+//                        cKDTree emission order + CPython set order; the tree is built level by level with one lane per node, the
+//                        traversal and the set order run on lane 0 out of LDS), NumPy-1.22 argsort of the sigmas -> keypoints in
+//                        adaptiveNMS's priority order
+//   K6 ssc_batch         ANMS.ssc (ssc.hip)
+//   K7 rt_append         [x, y] flip, vstack + drop exact duplicates keeping the first (getFeatures.py:109-112), keyframe
+//                        refresh (Mapping.py:59-66 with the frame's velocity), feature count
+// Slots are processed in chunks of `slots` lanes (scratch: 33 MB per slot); every kernel exits at once for slots beyond
 // the number of flagged lanes, which only the device knows.
 #include "roam_internal.h"
 #include "doh_common.h"
