@@ -829,18 +829,18 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
         if (e != hipSuccess) return e;
         const bool tr = trace && first == 0;
-        if (tr) hipEventRecord(trace[0], st);
+        if (tr && (e = hipEventRecord(trace[0], st)) != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
-        if (tr) hipEventRecord(trace[1], st);
+        if (tr && (e = hipEventRecord(trace[1], st)) != hipSuccess) return e;
         {
             const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
             const int64_t all = (int64_t)tx * ty * P;
             if (a.size1 != 15 || a.size2 != 30) return hipErrorInvalidValue;      // the engine's fixed detector parameters (box sizes are compile-time)
             hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
         }
-        if (tr) hipEventRecord(trace[2], st);
+        if (tr && (e = hipEventRecord(trace[2], st)) != hipSuccess) return e;
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
         e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, P, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, first);
