@@ -406,7 +406,7 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     # (profiles/pmc_run.sh -> profiles/pmc_traffic.py); null when no pass at this lane count is committed
     traffic, valu_frac, src = None, None, None
     kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_wave_kernel", "pyramid": "pyr_down_wave_kernel",
-             "doh_integral": "rt_integral_kernel", "doh_det_maxima": "rt_det_mask_kernel"}[dom]
+             "doh_integral": "rt_integral_kernel", "doh_det_maxima": "rt_det_strip_kernel"}[dom]
     for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))

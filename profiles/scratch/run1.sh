@@ -1,0 +1,7 @@
+set -u
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r03a
+timeout 900 python -m pytest tests/test_gpu_retrack.py tests/test_gpu_reference_dump.py -x -q -m gpu > gpurun_out/r03a/pytest_retrack.log 2>&1; echo "pytest rc $?"
+tail -5 gpurun_out/r03a/pytest_retrack.log
+ROAM_DET_TILES=1 timeout 300 python profiles/time_doh.py 512 > gpurun_out/r03a/doh_tiles.log 2>&1; cat gpurun_out/r03a/doh_tiles.log
+timeout 300 python profiles/time_doh.py 512 > gpurun_out/r03a/doh_strip.log 2>&1; cat gpurun_out/r03a/doh_strip.log

@@ -4,6 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from radarslampy_amd import _ffi, synth
+if os.environ.get("ROAM_LIB"):
+    _ffi.LIB_PATH = os.path.abspath(os.environ["ROAM_LIB"])      # an A/B build (profiles/build_variant.py)
 from radarslampy_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 recs, poses, feat = synth.make_sequence(5, 2, n_static=460, n_movers=24, distortion=True)

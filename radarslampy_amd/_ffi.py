@@ -7,7 +7,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libroam_hip.so")
+LIB_PATH = os.environ.get("ROAM_LIB") or os.path.join(_HERE, "csrc", "libroam_hip.so")     # ROAM_LIB: an A/B build (profiles/build_variant.py)
 
 ROAM_OK, ROAM_E_ARG, ROAM_E_HIP, ROAM_E_CAPACITY, ROAM_E_NODEVICE, ROAM_E_STATE = 0, -1, -2, -3, -4, -5
 MAX_FEATURES = 1024

@@ -6,10 +6,10 @@
 //                        staged in LDS), column cumsum in registers, row cumsum through double-buffered LDS tiles - both in NumPy's
 //                        sequential order, image written once.  Chunks of fewer than RI_MIN_DETECTIONS detections (and a lane's
 //                        first detection) take rt_integ_cols + rt_integ_rows instead: thousands of threads per detection
-//   K3 rt_det_mask       box-filter Hessian determinants of both live layers (sigma 5.005 / 10, sizes 15 / 30; the sigma 0.01 layer
-//                        is all-NaN in scikit-image and ignored) on 30 x 62 pixel tiles whose 62 x 94 block of the integral image is
-//                        staged in LDS; dxy boxes only where dxx*dyy can pass the threshold; 3x3x3 maxima above the threshold are
-//                        appended to the detection's candidate list
+//   K3 rt_det_strip      box-filter Hessian determinants of both live layers (sigma 5.005 / 10, sizes 15 / 30; the sigma 0.01 layer
+//                        is all-NaN in scikit-image and ignored): workgroups march down 62-column strips of the integral image with
+//                        its rows in an LDS ring (each byte fetched ~1.4 times); dxy boxes only where dxx*dyy can pass the
+//                        threshold; 3x3x3 maxima above the threshold are appended to the detection's candidate list
 //   K4 rt_emit           the candidates sorted into C (row, col, layer) order
 //   K5 rt_blobs          one wavefront per lane: response order, scikit-image's _prune_blobs in ITS pair order (blobprune.h:
 //                        cKDTree emission order + CPython set order; the tree is built level by level with one lane per node, the
@@ -392,128 +392,338 @@ __device__ __forceinline__ void rt_push_maxima(const RtArgs &a, int ls, int r, i
         }
 }
 
-// ------------------------------------------------------------------------------------------------ K3: determinants + maxima
-// Box sizes (15, 30) = int(3 sigma) of the engine's detector parameters, compile-time.  A workgroup of 8 waves owns a 30 x 62 pixel tile: with the one-pixel halo of the 3x3x3 maxima
-// that is a 32 x 64 grid of determinant positions (wave = row, lane = column, four rows per wave), which read the integral image at
-// rows r0-15 .. r0+46 and columns c0-15 .. c0+78 (box size 30: offsets -14 .. +16): that 62 x 94 block is staged in LDS once.
-// Determinants come from hessian_det_pruned (doh_common.h): a position whose dxx*dyy does not exceed the threshold skips the dxy
-// boxes.  Only max(layer 15, layer 30) per position goes to LDS; a pixel's own two determinants stay in registers, and the 3 x 3
-// neighbourhood is read only by waves that hold a candidate.
-#define RT_TH 30
-#define RT_TW 62
-#define RT_PR (RT_TH + 2)                  // 32 position rows
-#define RT_PC (RT_TW + 2)                  // 64 position columns
-#define RT_HALO 15                         // 1 (maxima halo) + 14 (lowest box offset of size 30)
-#define RT_BR (RT_PR + 14 + 16)            // 62 rows
-#define RT_BC (RT_PC + 14 + 16)            // 94 columns
-#define RT_BP 96                           // LDS pitch of the block: 3 x 32 staging columns (94 used)
-#define RT_DET_THREADS 512
-// persistent grid size: a PRIME, so that a workgroup's tiles (work = block, block + grid, ...) walk through every tile column and row -
-// with 4096 workgroups and 32 tile columns one workgroup in 16 received nothing but (slower) border tiles and set the kernel's time
-#ifndef RT_DET_GRID
-#define RT_DET_GRID 4093
+// ------------------------------------------------------------------------------------------------ K3: determinants + maxima (strip march)
+// Box sizes (15, 30) = int(3 sigma) of the engine's detector parameters, compile-time.  Round 2's kernel staged a 62 x 94 block of the
+// integral image per 30 x 62 outputs: every byte of the image was fetched 3.1 times and the L2 captured none of it (PMC: 53.7 GB per
+// 512 detections against 16.8 GB algorithmic).  Here a workgroup of 8 waves owns a column STRIP of 62 outputs (SD_HALVES = 2: 16
+// waves, 126 outputs) and marches DOWN the image: the rows of the integral image live in an LDS ring of 64 rows x 94 columns, every
+// step loads the SD_T NEW rows only (prefetched into registers three steps ahead) and computes SD_T x 64 determinant positions, so
+// a byte is fetched 94 / 62 = 1.5 times before L2 and 1.36 times from HBM (PMC; SD_HALVES = 2: 1.25 / 1.06, but one workgroup per
+// CU and 10 % slower) and the vertical halos (box rows and the 3 x 3 x 3 maxima) cost nothing: the maxima of a step's last row are
+// decided one step later from a two-row seam kept with the per-position maxima.
+//   * ONE barrier per step: the rows step t + 1 needs are written into ring slots that step t does not read (64 slots, 46 live
+//     rows, 16 new ones), the per-position maxima are double-buffered - staging, the maxima of step t - 1 and the determinants of
+//     step t run between the same two barriers, on different waves at different times.
+//   * ring addressing without arithmetic: the step loop is unrolled by four, so the ring row of (step phase, position row, box
+//     offset) is a compile-time constant; the wave's own row term (0..7) sits in the base register, and rows 0..7 of the ring are
+//     stored twice (also as rows 64..71) so that "constant + wave" never wraps.  DS offsets are 16 bits: two base registers per
+//     column (ring rows 0..35 / 36..71).
+//   * columns are clipped like skimage's _integ ONCE per thread: the twelve clipped corner columns of the dxx / dyy boxes are byte
+//     offsets in registers, so the strips along the left / right image border run the same code as interior ones; rows need clipping
+//     in the first and the last steps only (a variant with computed row offsets).  The dxy boxes (where dxx * dyy can pass the
+//     threshold: ~4 % of the wave-rows) compute their addresses on the fly.
+//   * the 16 boxes of a thread and step are ONE stream of 8 pairs, the reads of pair i + 1 issued before the arithmetic of pair i
+//     (sd_tile_fast); max(0, box) is the clamp modifier of the box's last subtraction (the ring holds the image scaled by 2^-10).
+//   * workgroup -> strip mapping is XCD-aware: the strips of a detection are consecutive workgroups of ONE XCD, started together
+//     and marching in step, so that the cache lines neighbouring strips share come from that XCD's L2 (hit rate 25 %).
+//   * a wave whose block of the image is (almost) empty - the corners beyond the maximum range - skips its step (see `dark`).
+#define SD_T 16                             // position rows per step
+#define SD_RING 64
+#define SD_DUP 8
+#ifndef SD_HALVES
+#define SD_HALVES 1                         // 64-column groups per workgroup (8 waves each); 1: two workgroups per CU
 #endif
-__global__ __launch_bounds__(RT_DET_THREADS, 4) void rt_det_mask_kernel(RtArgs a, int first, int P, int tiles_x, int tiles_y)
+#define SD_PC (64 * SD_HALVES)              // position columns per strip
+#define SD_OUT (SD_PC - 2)
+#define SD_HL 14                            // lowest / highest box offset of size 30
+#define SD_HR 16
+#define SD_BC (SD_PC + SD_HL + SD_HR)       // staged columns (158 | 94)
+#define SD_BP ((SD_BC + 15) / 16 * 16)      // ring pitch in doubles (160 | 96)
+#define SD_PITCHB (SD_BP * 8)
+#define SD_SPLIT 36
+#define SD_THREADS (512 * SD_HALVES)
+#define SD_RING_BYTES ((SD_RING + SD_DUP) * SD_PITCHB)
+#define SD_M2_ROWS (SD_T + 2)
+#define SD_LDS_BYTES (SD_RING_BYTES + 2 * SD_M2_ROWS * SD_PC * 8)
+#define SD_NST ((SD_T * SD_BP + SD_THREADS - 1) / SD_THREADS)   // staged elements per thread and step (3)
+extern __shared__ __align__(16) char sd_smem[];
+
+// The ring holds the integral image scaled by 2^-10 (an exact operation that commutes with every rounding below), so that a box sum -
+// at most 30 x 30 pixels of at most 1.0 - stays below 1 and skimage's max(0, sum) is the CLAMP output modifier of the box's last
+// subtraction instead of a v_max_f64 of its own (8 of a position's 46 vector instructions); the 1 / size^2 factors carry the 2^10.
+#define SD_SCALE 0.0009765625
+#define SD_UNSCALE 1024.0
+__device__ __forceinline__ double sd_box(double a, double d, double b, double c)
 {
-    __shared__ double sblk[RT_BR * RT_BP];
-    __shared__ double m2[RT_PR][RT_PC];
-    const int nact = min(P, max(0, *a.rt_n - first));
-    const int per = tiles_x * tiles_y;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int W = a.W, H = a.W;
-    const double thr = a.threshold;
-    // the block of a tile travels global -> registers -> LDS; the loads of the NEXT tile are issued before the arithmetic of the
-    // current one, so that the L2 latency (69 % TCP pending stall when staged in place) hides behind it.  Thread t stages rows
-    // (t / 32) + 16 q, columns (t % 32) + 32 p: no division, and in interior tiles every offset is an immediate
-    double stage[4][3];
-    const int srow = t >> 5, scol = t & 31;
-    auto fetch = [&](int work) {
-        const int ls = work / per, trem = work - ls * per;
-        const double *S = a.S + (int64_t)ls * a.SP * W;
-        const int SP = a.SP;
-        const int rbase = (trem / tiles_x) * RT_TH - RT_HALO, cbase = (trem % tiles_x) * RT_TW - RT_HALO;
-        if (rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W) {
-            const double *q = S + (int64_t)(rbase + srow) * SP + cbase + scol;
+    const double t = __dsub_rn(__dadd_rn(a, d), b);
+    double r;
+    asm("v_add_f64 %0, %1, -%2 clamp" : "=v"(r) : "v"(t), "v"(c));
+    return r;
+}
+template <int SIZE> __device__ __forceinline__ double sd_wi() { return __dmul_rn(__ddiv_rn(__ddiv_rn(1.0, (double)SIZE), (double)SIZE), SD_UNSCALE); }
+
+__device__ __forceinline__ double sd_ldr(const uint32_t (&ca)[12], const uint32_t (&cb)[12], int row, int j)
+{
+    const int rr = ((row % SD_RING) + SD_RING) % SD_RING;                  // (constants after unrolling)
+    return rr < SD_SPLIT ? *reinterpret_cast<const double *>(sd_smem + (ca[j] + rr * SD_PITCHB))
+                         : *reinterpret_cast<const double *>(sd_smem + (cb[j] + (rr - SD_SPLIT) * SD_PITCHB));
+}
+
+// dxx * dyy (hessian_det_pruned's first product) of a thread's two positions in a step whose box rows need no clipping; PH = step & 3.
+// The 16 boxes are ONE stream of 8 pairs (the same box of both positions): the eight corner reads of pair i + 1 are issued before the
+// arithmetic of pair i (the compiler's own order waited for every box's reads before it issued the next four), and the two
+// positions' dependent float64 chains alternate instruction by instruction, so that a wave that is alone on its SIMD - the tail of
+// every step: the hardware favours the oldest wave, the youngest finish last - still issues back to back.
+template <int PH>
+__device__ __forceinline__ void sd_tile_fast(const uint32_t (&ca)[12], const uint32_t (&cb)[12], double (&d0)[SD_T / 8], double (&d1)[SD_T / 8])
+{
+    static_assert(SD_T == 16, "two positions per thread and step");
+    double v[2][2][4];                                                     // [pair slot][position][corner]
+    auto issue = [&](int i, double(&o)[2][4]) {
+        const int L = (i >> 2) & 1, q = i & 3;                             // q: xx-mid, xx-side, yy-mid, yy-side (hessian_box 4..7)
+        const int SIZE = L ? 30 : 15, s2 = (SIZE - 1) / 2, s3 = SIZE / 3;
+        const int ra = q < 2 ? -s3 + 1 : (q == 2 ? -s2 : -(s3 / 2)), rb = ra + (q < 2 ? 2 * s3 - 1 : (q == 2 ? SIZE : s3));
+        const int ja = 6 * L + (q == 0 ? 0 : (q == 1 ? 2 : 4)), jb = ja + 1;
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++)
-                if (qq < 3 || srow + 48 < RT_BR) {
-                    stage[qq][0] = q[qq * 16 * SP]; stage[qq][1] = q[qq * 16 * SP + 32];
-                    if (scol + 64 < RT_BC) stage[qq][2] = q[qq * 16 * SP + 64];
-                }
-        } else {
-            // source indices clipped at the image border: skimage's clipped corner indices never leave the block
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const double *q = S + (int64_t)clipi(rbase + srow + 16 * qq, 0, H - 1) * SP;
-#pragma unroll
-                for (int pp = 0; pp < 3; pp++) stage[qq][pp] = q[clipi(cbase + scol + 32 * pp, 0, W - 1)];
-            }
+        for (int k = 0; k < 2; k++) {
+            const int R0 = SD_T * PH + 8 * k;
+            o[k][0] = sd_ldr(ca, cb, R0 + ra, ja); o[k][1] = sd_ldr(ca, cb, R0 + rb, jb);
+            o[k][2] = sd_ldr(ca, cb, R0 + ra, jb); o[k][3] = sd_ldr(ca, cb, R0 + rb, ja);
         }
     };
-    // the maxima of a tile are looked for one iteration later, between the two barriers of the next tile's staging (every thread
-    // has written its per-position maxima by then, nobody overwrites them before the second barrier): two barriers per tile
-    double d0[4], d1[4];
-    int pls = -1, pr0 = 0, pc0 = 0;                                        // the tile whose maxima are pending
-    auto maxima = [&]() {
+    issue(0, v[0]);
+    double mid[2] = {0.0, 0.0}, dxx[2] = {0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int rr = k * 8 + wave, r = pr0 - 1 + rr, c = pc0 - 1 + lane;
-            if (rr < 1 || rr > RT_TH || lane < 1 || lane > RT_TW || r >= H || c >= W) continue;
-            uint32_t bits = 0;
-            if (d0[k] > thr || d1[k] > thr) {
-                // 3x3x3 footprint = the 9 per-position maxima around the pixel (the pixel's own included)
-                double m = m2[rr][lane];
-#pragma unroll
-                for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-                    for (int dc = -1; dc <= 1; dc++) { const double u = m2[rr + dr][lane + dc]; m = u > m ? u : m; }
-                bits = ((d0[k] > thr && !(m > d0[k])) ? 1u : 0u) | ((d1[k] > thr && !(m > d1[k])) ? 2u : 0u);
-            }
-            if (bits) rt_push_maxima(a, pls, r, c, bits, d0[k], d1[k]);
+    for (int i = 0; i < 8; i++) {
+        if (i + 1 < 8) issue(i + 1, v[(i + 1) & 1]);
+        const int L = (i >> 2) & 1, q = i & 3;
+        const double(&x)[2][4] = v[i & 1];
+        double t0 = __dadd_rn(x[0][0], x[0][1]), t1 = __dadd_rn(x[1][0], x[1][1]);
+        t0 = __dsub_rn(t0, x[0][2]); t1 = __dsub_rn(t1, x[1][2]);
+        double b0, b1;
+        asm("v_add_f64 %0, %1, -%2 clamp" : "=v"(b0) : "v"(t0), "v"(x[0][3]));
+        asm("v_add_f64 %0, %1, -%2 clamp" : "=v"(b1) : "v"(t1), "v"(x[1][3]));
+        if (q == 0 || q == 2) { mid[0] = b0; mid[1] = b1; }
+        else {
+            const double w_i = L ? sd_wi<30>() : sd_wi<15>();
+            double m0 = __dmul_rn(3.0, b0), m1 = __dmul_rn(3.0, b1);
+            double e0 = __dsub_rn(mid[0], m0), e1 = __dsub_rn(mid[1], m1);
+            e0 = __dmul_rn(-e0, w_i); e1 = __dmul_rn(-e1, w_i);
+            if (q == 1) { dxx[0] = e0; dxx[1] = e1; }
+            else if (L) { d1[0] = __dmul_rn(dxx[0], e0); d1[1] = __dmul_rn(dxx[1], e1); }
+            else { d0[0] = __dmul_rn(dxx[0], e0); d0[1] = __dmul_rn(dxx[1], e1); }
         }
-    };
-    if ((int)blockIdx.x < nact * per) fetch(blockIdx.x);
-    for (int work = blockIdx.x; work < nact * per; work += gridDim.x) {
-        const int ls = work / per, trem = work - ls * per;
-        const int r0 = (trem / tiles_x) * RT_TH, c0 = (trem % tiles_x) * RT_TW;
-        const int rbase = r0 - RT_HALO, cbase = c0 - RT_HALO;
-        const bool interior = rbase >= 0 && rbase + RT_BR <= H && cbase >= 0 && cbase + RT_BC <= W;
-        __syncthreads();                                                   // the previous tile's corner reads and maxima writes are done
-#pragma unroll
-        for (int qq = 0; qq < 4; qq++)
-            if (qq < 3 || srow + 48 < RT_BR) {
-#pragma unroll
-                for (int pp = 0; pp < 3; pp++) sblk[(srow + 16 * qq) * RT_BP + scol + 32 * pp] = stage[qq][pp];
-            }
-        if (pls >= 0) maxima();
-        __syncthreads();
-        if (work + (int)gridDim.x < nact * per) fetch(work + gridDim.x);
-        if (interior) {
-            const DohLdsAcc<RT_BP> acc = {sblk, rbase, cbase};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
-                d0[k] = hessian_det_pruned<15>(acc, r, c, thr);
-                d1[k] = hessian_det_pruned<30>(acc, r, c, thr);
-                m2[rr][lane] = d1[k] > d0[k] ? d1[k] : d0[k];
-            }
-        } else {
-            const DohLdsClipAcc<RT_BP> acc = {sblk, rbase, cbase, H, W};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int rr = k * 8 + wave, r = r0 - 1 + rr, c = c0 - 1 + lane;
-                double u0 = 0.0, u1 = 0.0;                                 // outside the image: nothing that could exceed a maximum
-                if (r >= 0 && r < H && c >= 0 && c < W) {
-                    u0 = hessian_det_pruned<15>(acc, r, c, thr);
-                    u1 = hessian_det_pruned<30>(acc, r, c, thr);
-                }
-                d0[k] = u0; d1[k] = u1;
-                m2[rr][lane] = u1 > u0 ? u1 : u0;
-            }
-        }
-        pls = ls; pr0 = r0; pc0 = c0;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (pls >= 0) { __syncthreads(); maxima(); }
+}
+
+// the same product with the box rows clipped to the image (first / last steps of a strip): r = image row of the position (wave-uniform)
+template <int SIZE, int L>
+__device__ __forceinline__ double sd_det_rows(const uint32_t (&ca)[12], int w8, int r, int H)
+{
+    constexpr int s2 = (SIZE - 1) / 2, s3 = SIZE / 3, w = SIZE, J = 6 * L;
+    const double w_i = sd_wi<SIZE>();
+    auto ld = [&](int row, int j) { return *reinterpret_cast<const double *>(sd_smem + (ca[j] + (uint32_t)(((row & (SD_RING - 1)) - w8) * SD_PITCHB))); };
+    const int xa = clipi(r - s3 + 1, 0, H - 1), xb = clipi(xa + 2 * s3 - 1, 0, H - 1);
+    double mid = sd_box(ld(xa, J + 0), ld(xb, J + 1), ld(xa, J + 1), ld(xb, J + 0));
+    double side = sd_box(ld(xa, J + 2), ld(xb, J + 3), ld(xa, J + 3), ld(xb, J + 2));
+    double dxx = __dsub_rn(mid, __dmul_rn(3.0, side));
+    dxx = __dmul_rn(-dxx, w_i);
+    const int ya = clipi(r - s2, 0, H - 1), yb = clipi(ya + w, 0, H - 1), za = clipi(r - s3 / 2, 0, H - 1), zb = clipi(za + s3, 0, H - 1);
+    mid = sd_box(ld(ya, J + 4), ld(yb, J + 5), ld(ya, J + 5), ld(yb, J + 4));
+    side = sd_box(ld(za, J + 4), ld(zb, J + 5), ld(za, J + 5), ld(zb, J + 4));
+    double dyy = __dsub_rn(mid, __dmul_rn(3.0, side));
+    dyy = __dmul_rn(-dyy, w_i);
+    return __dmul_rn(dxx, dyy);
+}
+
+// the dxy term of a position whose dxx * dyy passes the threshold (rare): addresses computed on the fly, clipping included
+template <int SIZE>
+__device__ __forceinline__ double sd_dxy(double det, int r, int c, int H, int W, int cbase)
+{
+    constexpr int s3 = SIZE / 3;
+    const double w_i = sd_wi<SIZE>();
+    const int r0 = clipi(r - s3, 0, H - 1), r1 = clipi(r0 + s3, 0, H - 1), r2 = clipi(r + 1, 0, H - 1), r3 = clipi(r2 + s3, 0, H - 1);
+    const int c0 = clipi(c - s3, 0, W - 1), c1 = clipi(c0 + s3, 0, W - 1), c2 = clipi(c + 1, 0, W - 1), c3 = clipi(c2 + s3, 0, W - 1);
+    auto at = [&](int rr, int cc) { return *reinterpret_cast<const double *>(sd_smem + (((rr & (SD_RING - 1)) * SD_BP + (cc - cbase)) * 8)); };
+    const double tl = sd_box(at(r0, c0), at(r1, c1), at(r0, c1), at(r1, c0));
+    const double br = sd_box(at(r2, c2), at(r3, c3), at(r2, c3), at(r3, c2));
+    const double bl = sd_box(at(r0, c2), at(r1, c3), at(r0, c3), at(r1, c2));
+    const double tr = sd_box(at(r2, c0), at(r3, c1), at(r2, c1), at(r3, c0));
+    double dxy = __dsub_rn(__dsub_rn(__dadd_rn(bl, tr), tl), br);
+    dxy = __dmul_rn(-dxy, w_i);
+    return __dsub_rn(det, __dmul_rn(0.81, __dmul_rn(dxy, dxy)));
+}
+
+template <int P> struct SdTag { static constexpr int value = P; };
+
+__global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int first, int P, int nstrips)
+{
+    const int nact = min(P, max(0, *a.rt_n - first));
+    // XCD-aware order: workgroup id -> (XCD = id % 8, j = id / 8); XCD x owns the x-th contiguous eighth of the (detection, strip) list
+    const int total = nact * nstrips, per = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int work = xcd * per + jq;
+    if (jq >= per || work >= total) return;
+    const int ls = work / nstrips, strip = work - ls * nstrips;
+    const int W = a.W, H = a.W, SP = a.SP;
+    const double thr = a.threshold;
+    const double dark_sum = 225.0 * sqrt(thr) * 0.5 * 0.95 * SD_SCALE;       // (5 % under the bound: the sums are rounded; ring units)
+    const double *__restrict__ S = a.S + (int64_t)ls * SP * W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), w8 = wave & 7, half = wave >> 3;   // half < SD_HALVES
+    const int c0 = strip * SD_OUT, cbase = c0 - 1 - SD_HL;
+    const int pc = half * 64 + lane, c = c0 - 1 + pc;
+    const bool cvalid = c >= 0 && c < W;
+    const bool wave_live = c0 - 1 + half * 64 < W;                          // some column of this wave lies inside the image
+    // per-position maxima max(layer 15, layer 30), two buffers by step parity, SD_M2_ROWS x SD_PC each: rows 0, 1 = the seam (rows 14, 15
+    // of the step before), row 2 + r = position row r.  mb = this thread's column in row 0 of buffer 0 (byte offset)
+    constexpr int M2ROW = SD_PC * 8, M2BUF = SD_M2_ROWS * M2ROW;
+    const uint32_t mb = (uint32_t)(SD_RING_BYTES + w8 * M2ROW + pc * 8);
+    auto m2at = [&](int buf, int row, int dc) -> double & { return *reinterpret_cast<double *>(sd_smem + (mb + (uint32_t)(buf * M2BUF + (row - w8) * M2ROW + dc * 8))); };
+    // the twelve clipped corner columns (skimage _integ: c' = clip(c + off), c'' = clip(c' + width)) as ring byte offsets
+    uint32_t ca[12], cb[12];
+    {
+        constexpr int off[6][2] = {{-7, 15}, {-2, 5}, {-4, 9}, {-14, 30}, {-5, 10}, {-9, 19}};
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int x0 = clipi(c + off[q][0], 0, W - 1), x1 = clipi(x0 + off[q][1], 0, W - 1);
+            ca[2 * q] = (uint32_t)((w8 * SD_BP + (x0 - cbase)) * 8);
+            ca[2 * q + 1] = (uint32_t)((w8 * SD_BP + (x1 - cbase)) * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; q++) cb[q] = ca[q] + SD_SPLIT * SD_PITCHB;
+    }
+    // staging: the SD_T x SD_BP new elements of a step in linear order over the threads (element e = tid + SD_THREADS j: a wave reads runs
+    // of 512 contiguous bytes); a thread's (row, column) pairs are fixed, the image base moves: loads are "uniform base + lane offset".
+    // The rows of step t are loaded three steps ahead into one of two register sets (HBM latency is longer than a step)
+    const bool strip_inside = cbase >= 0 && cbase + SD_BP <= W;
+    uint32_t goff[SD_NST], loff[SD_NST];                                   // byte offsets: image (from row 16 t + 16, column cbase) / ring (from slot 16 q)
+    int srow[SD_NST], scol[SD_NST];
+#pragma unroll
+    for (int j = 0; j < SD_NST; j++) {
+        const int e = tid + SD_THREADS * j;
+        srow[j] = e / SD_BP; scol[j] = e - srow[j] * SD_BP;
+        goff[j] = (uint32_t)((srow[j] * SP + scol[j]) * 8);
+        loff[j] = (uint32_t)(srow[j] * SD_PITCHB + scol[j] * 8);
+    }
+    double stage[2][SD_NST];
+    int frow = 0;                                                          // first image row of the next load: 16 t + 16, t = -1, 0, ..
+    auto fetch = [&](double(&st)[SD_NST]) {
+        const char *base = reinterpret_cast<const char *>(S + (int64_t)frow * SP + cbase);     // (wave-uniform)
+        if (frow >= 0 && frow + SD_T <= H && strip_inside) {
+#pragma unroll
+            for (int j = 0; j < SD_NST; j++)
+                if (SD_THREADS * (j + 1) <= SD_T * SD_BP || tid + SD_THREADS * j < SD_T * SD_BP) st[j] = *reinterpret_cast<const double *>(base + goff[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SD_NST; j++) {
+                const int gr = frow + srow[j], col = cbase + scol[j];
+                if (srow[j] < SD_T && gr >= 0 && gr < H && col >= 0 && col < W) st[j] = *reinterpret_cast<const double *>(base + goff[j]);
+            }
+        }
+        frow += SD_T;
+    };
+    // ring slot of row 16 t + 16 + srow = 16 ((t + 1) & 3) + srow; slots 0..7 are mirrored at 64..71
+    auto put = [&](int quarter, const double(&st)[SD_NST]) {
+#pragma unroll
+        for (int j = 0; j < SD_NST; j++)
+            if (SD_THREADS * (j + 1) <= SD_T * SD_BP || tid + SD_THREADS * j < SD_T * SD_BP) {
+                double *d = reinterpret_cast<double *>(sd_smem + (loff[j] + (uint32_t)(quarter * SD_T * SD_PITCHB)));
+                const double v = __dmul_rn(st[j], SD_SCALE);
+                *d = v;
+                if (quarter == 0 && srow[j] < SD_DUP) d[SD_RING * SD_BP] = v;
+            }
+    };
+    double d0[SD_T / 8], d1[SD_T / 8], p0 = 0.0, p1 = 0.0;                 // this step's determinants; the last row of the step before
+    uint32_t cand = 0, pcand = 0;                                          // bit k: position k of the step holds a determinant above the threshold
+#pragma unroll
+    for (int k = 0; k < SD_T / 8; k++) { d0[k] = 0.0; d1[k] = 0.0; }
+    // 3 x 3 x 3 maxima out of buffer `buf`: rr2 = row in the buffer (2 + position row; 1 = the seam row), r = image row
+    auto decide = [&](int buf, int rr2, int r, double v0, double v1) {
+        if (pc < 1 || pc > SD_OUT || c >= W || r >= H) return;
+        double mx = m2at(buf, rr2, 0);
+#pragma unroll
+        for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+            for (int dc = -1; dc <= 1; dc++) { const double u = m2at(buf, rr2 + dr, dc); mx = u > mx ? u : mx; }
+        const uint32_t bits = ((v0 > thr && !(mx > v0)) ? 1u : 0u) | ((v1 > thr && !(mx > v1)) ? 2u : 0u);
+        if (bits) rt_push_maxima(a, ls, r, c, bits, v0, v1);
+    };
+    // maxima of step pt (rows 0 .. SD_T - 2) and of the last row of the step before it; everything they need is in step pt's buffer
+    auto maxima = [&](int pt, int buf) {
+        if (w8 == 7) {
+            if (pcand) decide(buf, 1, SD_T * pt - 1, p0, p1);
+            p0 = d0[SD_T / 8 - 1]; p1 = d1[SD_T / 8 - 1]; pcand = cand >> (SD_T / 8 - 1);
+        }
+        if (cand) {
+#pragma unroll
+            for (int k = 0; k < SD_T / 8; k++) {
+                const int rr = 8 * k + w8;
+                if (((cand >> k) & 1u) && rr < SD_T - 1) decide(buf, 2 + rr, SD_T * pt + rr, d0[k], d1[k]);
+            }
+        }
+    };
+    const int nt = H / SD_T + 1;                                           // the last step's last row lies outside the image
+    // prologue: per-position maxima cleared (rows above the image count as zero), rows 0..31 of the image, loads of steps 1 and 2 in flight
+    for (int i = tid; i < 2 * SD_M2_ROWS * SD_PC; i += SD_THREADS) reinterpret_cast<double *>(sd_smem + SD_RING_BYTES)[i] = 0.0;
+    fetch(stage[1]);
+    fetch(stage[0]);
+    put(0, stage[1]);
+    put(1, stage[0]);
+    fetch(stage[1]);
+    fetch(stage[0]);
+    __syncthreads();
+    auto step = [&](auto tag, int t) {
+        constexpr int PH = decltype(tag)::value, WB = PH & 1;
+        // rows of step t + 1 (loaded two steps ago) into slots that step t does not read; then the loads of step t + 3
+        put((PH + 2) & 3, stage[(PH + 1) & 1]);
+        fetch(stage[(PH + 1) & 1]);
+        if (t >= 1) maxima(t - 1, WB ^ 1);
+        const int rbase = SD_T * t;
+        const bool fast = t >= 1 && rbase + SD_T - 1 + SD_HR <= H - 1;
+        // A wave whose positions see (almost) nothing skips the step: every box of every one of its positions lies inside the block
+        // rows (rbase + w8 - 14, rbase + w8 + 8 (SD_T / 8 - 1) + 16] x columns (first - 14, last + 16], boxes are >= 0, and with the block's
+        // sum T: |dxx| = |2 side - rest| / 225 <= 2 T / 225, likewise dyy, so dxx * dyy <= 4 T^2 / 225^2 <= threshold for
+        // T <= 225 sqrt(0.0005) / 2 = 2.51 (size 30: 10.06).  Such products can neither pass nor exceed a passing neighbour - they
+        // count as 0.  (The corners of the Cartesian image beyond the maximum range, 21 % of it, are exactly zero.)
+        bool dark = false;
+        if (wave_live) {
+            const int ra = max(rbase + w8 - SD_HL, 0), rb = min(rbase + w8 + 8 * (SD_T / 8 - 1) + SD_HR, H - 1);
+            const int xa = clipi(c0 - 1 + half * 64 - SD_HL, 0, W - 1), xb = clipi(c0 - 1 + half * 64 + 63 + SD_HR, 0, W - 1);
+            auto at = [&](int rr, int cc) { return *reinterpret_cast<const double *>(sd_smem + (((rr & (SD_RING - 1)) * SD_BP + (cc - cbase)) * 8)); };
+            const double tsum = __dsub_rn(__dsub_rn(__dadd_rn(at(ra, xa), at(rb, xb)), at(ra, xb)), at(rb, xa));
+            dark = __builtin_amdgcn_readfirstlane(tsum <= dark_sum ? 1 : 0) != 0;
+        }
+        if (!wave_live || dark) {
+#pragma unroll
+            for (int k = 0; k < SD_T / 8; k++) { d0[k] = 0.0; d1[k] = 0.0; }
+        } else if (fast) {
+            sd_tile_fast<PH>(ca, cb, d0, d1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SD_T / 8; k++) {
+                const int r = rbase + 8 * k + w8;
+                d0[k] = r < H ? sd_det_rows<15, 0>(ca, w8, r, H) : 0.0;
+                d1[k] = r < H ? sd_det_rows<30, 1>(ca, w8, r, H) : 0.0;
+            }
+        }
+        cand = 0;
+#pragma unroll
+        for (int k = 0; k < SD_T / 8; k++) {
+            const int rr = 8 * k + w8, r = rbase + rr;
+            double mx = fmax(d0[k], d1[k]);
+            if (mx > thr) {
+                // (rare) the dxy term, hessian_det_pruned's second half.  A product that stays at or below the threshold can neither
+                // pass nor exceed a passing neighbour, so it goes to the maxima buffer as it is
+                if (d0[k] > thr) d0[k] = sd_dxy<15>(d0[k], r, c, H, W, cbase);
+                if (d1[k] > thr) d1[k] = sd_dxy<30>(d1[k], r, c, H, W, cbase);
+                if (!cvalid) { d0[k] = 0.0; d1[k] = 0.0; }                 // outside the image: nothing that could exceed a maximum
+                mx = fmax(d0[k], d1[k]);
+                if (mx > thr) cand |= 1u << k;
+            }
+            if (k == SD_T / 8 - 1 && w8 >= 6) m2at(WB, rr - (SD_T - 2), 0) = m2at(WB ^ 1, 2 + rr, 0);   // the seam: the last two rows of the step before
+            m2at(WB, 2 + rr, 0) = mx;
+        }
+        __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 4) {
+        step(SdTag<0>(), t);
+        if (t + 1 < nt) step(SdTag<1>(), t + 1);
+        if (t + 2 < nt) step(SdTag<2>(), t + 2);
+        if (t + 3 < nt) step(SdTag<3>(), t + 3);
+    }
+    maxima(nt - 1, (nt - 1) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------ K4: ordered candidates
@@ -818,7 +1028,19 @@ __global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
 // ------------------------------------------------------------------------------------------------ launcher
 hipError_t retrack_init()
 {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_det_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS_BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(rt_integral_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RI_LDS_BYTES);
+}
+
+// determinants + maxima of the first P scratch slots of a chunk
+static hipError_t launch_det(hipStream_t st, const RtArgs &a, int first, int P)
+{
+    const int W = a.W;
+    if (a.size1 != 15 || a.size2 != 30) return hipErrorInvalidValue;      // the engine's fixed detector parameters (box sizes are compile-time)
+    const int ns = (W + SD_OUT - 1) / SD_OUT;
+    hipLaunchKernelGGL(rt_det_strip_kernel, dim3((unsigned)(((int64_t)P * ns + 7) / 8 * 8)), dim3(SD_THREADS), SD_LDS_BYTES, st, a, first, P, ns);
+    return hipGetLastError();
 }
 
 hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace)
@@ -834,12 +1056,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
         if (tr && (e = hipEventRecord(trace[1], st)) != hipSuccess) return e;
-        {
-            const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
-            const int64_t all = (int64_t)tx * ty * P;
-            if (a.size1 != 15 || a.size2 != 30) return hipErrorInvalidValue;      // the engine's fixed detector parameters (box sizes are compile-time)
-            hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, first, P, tx, ty);
-        }
+        if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(trace[2], st)) != hipSuccess) return e;
         hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
@@ -870,9 +1087,7 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
     } else {
         hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
         if (e != hipSuccess) return e;
-        const int tx = (W + RT_TW - 1) / RT_TW, ty = (W + RT_TH - 1) / RT_TH;
-        const int64_t all = (int64_t)tx * ty * P;
-        hipLaunchKernelGGL(rt_det_mask_kernel, dim3((unsigned)std::min<int64_t>(all, RT_DET_GRID)), dim3(RT_DET_THREADS), 0, st, a, 0, P, tx, ty);
+        return launch_det(st, a, 0, P);
     }
     return hipGetLastError();
 }

@@ -261,3 +261,42 @@ def test_step_results_ring_does_not_drain_the_pipeline():
     for k, (x, y) in enumerate(zip(a, b)):
         assert x.tobytes() == y.tobytes(), k
     ctx.close()
+
+
+def _blob_payload(clip, seed, rows=400):
+    """speckle + Gaussian blobs in (azimuth, range), a third of them at the far end of the range axis = along the borders of the
+    Cartesian image, where the box corners of the determinant are clipped"""
+    rng = np.random.default_rng(seed)
+    img = rng.exponential(6.0, size=(rows, clip))
+    for i in range(max(18, clip // 5)):
+        a, A = rng.uniform(0, rows), rng.uniform(80, 200)
+        r = rng.uniform(clip - 24, clip - 2) if i % 3 == 0 else rng.uniform(4, clip - 2)
+        sa, sr = max(1.5, 240.0 / max(r, 4.0)), rng.uniform(2.0, 7.0)
+        aa = np.arange(int(a - 4 * sa), int(a + 4 * sa) + 1)
+        rr = np.arange(max(0, int(r - 4 * sr)), min(clip, int(r + 4 * sr) + 1))
+        img[np.ix_(aa % rows, rr)] += A * np.exp(-0.5 * ((aa - a) / sa) ** 2)[:, None] * np.exp(-0.5 * ((rr - r) / sr) ** 2)[None, :]
+    return np.clip(np.floor(img), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("clip", [132, 300, 508, 1020])
+def test_detection_on_image_sizes_that_do_not_fill_the_strips(clip):
+    """the determinant kernel marches 126-column strips in steps of 32 rows: images of 132 ... 1020 pixels end inside a strip and
+    inside a step (last strip 6 ... 12 columns wide), most of their positions clip box corners at the border, and blobs sit on
+    the border itself - detections must equal the oracle's getFeatures"""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    pay = _blob_payload(clip, clip)
+    ctx = _ffi.Context(0)
+    eng = Engine(2, 2, ctx=ctx, rows=pay.shape[0], stride=clip, payload_off=0, clip=clip, retrack_on_device=True)
+    eng.upload_scan(0, pay)
+    eng.upload_scan(1, np.ascontiguousarray(pay[::-1]))
+    for b in range(2):
+        eng.init_lane_detect(b, b, np.zeros(3))
+        src = pay if b == 0 else np.ascontiguousarray(pay[::-1])
+        cart = oracle.convertPolarImageToCartesian(src.astype(np.float32) / np.float32(255.))
+        want = oracle.append_dedupe(np.empty((0, 2)), _detect(cart))
+        got = eng.lane_features(b)
+        assert len(want) >= 15, len(want)
+        assert np.array_equal(got, want), (clip, b, len(got), len(want))
+    eng.close()
+    ctx.close()
