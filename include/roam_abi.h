@@ -204,6 +204,8 @@ int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *
  * bytes of every row that the path reads cross PCIe) on a copy stream that
  * overlaps the compute stream).  roam_engine_step waits for every upload enqueued before it;
  * roam_engine_fence makes later uploads wait for the steps enqueued so far (double-buffered pools). */
+/* host_records must be pinned / registered host memory (the copy kernel reads it from the GPU): a pageable pointer is refused
+ * with ROAM_E_ARG */
 int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t n, const uint8_t *host_records, int64_t host_stride);
 int32_t roam_engine_fence(roam_ctx *ctx);
 /* device-to-device copy of a resident record (lets a benchmark give every lane its own copy of a
@@ -222,8 +224,8 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
 int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx);
 /* blocking: fetch the per-lane results of the last step */
 int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
-/* per-step results without draining the pipeline: every step's records are copied to pinned host memory on a side stream
- * (ring of the last 8 steps); this call waits for step `step` only (0-based count of roam_engine_step calls) - poses and
+/* per-step results without draining the pipeline: every step's records are copied to pinned host memory right behind the step
+ * on the compute stream (ring of the last 8 steps); this call waits for step `step` only (0-based count of roam_engine_step calls) - poses and
  * flags of step N can be consumed while steps N+1.. are still running.  ROAM_E_STATE if the step left the ring. */
 int32_t roam_engine_step_results(roam_ctx *ctx, int64_t step, roam_lane_result *out, int32_t n);
 int32_t roam_engine_steps_enqueued(roam_ctx *ctx, int64_t *nstep);
@@ -233,6 +235,9 @@ int32_t roam_engine_set_retrack(roam_ctx *ctx, int32_t mode);
 /* like roam_engine_init_lane, but the initial features are DETECTED on the device from the pool scan
  * (appendNewFeatures(prevImgCart, empty), RawROAMSystem.py:150); needs cfg.retrack_on_device */
 int32_t roam_engine_init_lane_detect(roam_ctx *ctx, int32_t lane, int32_t pool_idx, const double *pose3);
+/* the same for the n lanes lane0 .. lane0 + n - 1 in one pass (pool_idx[n], poses3[n][3]): one warp / pyramid launch and one
+ * detection pass over all of them instead of n single-lane passes */
+int32_t roam_engine_init_lanes_detect(roam_ctx *ctx, int32_t lane0, int32_t n, const int32_t *pool_idx, const double *poses3);
 /* blocking: current feature set of a lane (cap rows), and its peak list */
 int32_t roam_engine_lane_features(roam_ctx *ctx, int32_t lane, float *pts, int32_t cap, int32_t *K);
 int32_t roam_engine_lane_peaks(roam_ctx *ctx, int32_t lane, int32_t *out, int64_t cap, int64_t *n);
@@ -304,6 +309,15 @@ typedef struct roam_keyframe_hdr {
  * device buffer (two ncclBroadcast calls: header + features, then the peak list), then copy it to the caller's arrays:
  * locals_xy (cap_pts, 2) f64, peaks (peaks_cap, 2) i32.  Either array may be NULL (its part is then not copied out). */
 int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyframe_hdr *hdr_out, double *locals_xy,
+                            int32_t cap_pts, int32_t *peaks, int64_t peaks_cap);
+
+/* The consumer of that broadcast: Map.addKeyframe (Mapping.py:118-147) on EVERY rank.  After roam_remote_map_reserve(n) each
+ * roam_bcast_keyframe also appends the received payload {header, prunedUndistortedLocals, polar peaks} device-to-device to a
+ * ring of n keyframes in this rank's HBM (the oldest is overwritten); the sending rank included, so all ranks hold the same
+ * global map.  count: keyframes received so far / resident now; get: index 0 = the oldest resident one. */
+int32_t roam_remote_map_reserve(roam_ctx *ctx, int32_t keyframes);
+int32_t roam_remote_map_count(roam_ctx *ctx, int64_t *received, int32_t *resident);
+int32_t roam_remote_map_get(roam_ctx *ctx, int32_t index, roam_keyframe_hdr *hdr_out, int32_t *root_out, double *locals_xy,
                             int32_t cap_pts, int32_t *peaks, int64_t peaks_cap);
 
 #ifdef __cplusplus

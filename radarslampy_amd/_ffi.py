@@ -79,6 +79,7 @@ _SIGS = {
     "roam_engine_steps_enqueued": (C.c_int32, [_vp, _P(C.c_int64)]),
     "roam_engine_set_retrack": (C.c_int32, [_vp, C.c_int32]),
     "roam_engine_init_lane_detect": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp]),
+    "roam_engine_init_lanes_detect": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     "roam_engine_lane_features": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_lane_peaks": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
     "roam_engine_doh_maxima": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32, C.c_double, _vp, _vp, C.c_int32, _P(C.c_int32)]),
@@ -100,6 +101,9 @@ _SIGS = {
     "roam_comm_allreduce_f64": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
     "roam_comm_barrier": (C.c_int32, [_vp]),
     "roam_bcast_keyframe": (C.c_int32, [_vp, C.c_int32, C.c_int32, _P(KeyframeHdr), _vp, C.c_int32, _vp, C.c_int64]),
+    "roam_remote_map_reserve": (C.c_int32, [_vp, C.c_int32]),
+    "roam_remote_map_count": (C.c_int32, [_vp, _P(C.c_int64), _P(C.c_int32)]),
+    "roam_remote_map_get": (C.c_int32, [_vp, C.c_int32, _P(KeyframeHdr), _P(C.c_int32), _vp, C.c_int32, _vp, C.c_int64]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 

@@ -84,6 +84,11 @@ struct Engine {
     bool rt_on = false;
     int rt_mode = 1;                                // 0 = suspended, 1 = lanes that ran out of features, 2 = every lane (measurement)
     uint8_t *kfb = nullptr;                         // 8e: packed keyframe payload (RCCL broadcast buffer)
+    // 8e consumer: the global map of Mapping.Map.addKeyframe on EVERY rank - a ring of received keyframe payloads in HBM
+    uint8_t *rmap = nullptr;
+    int rmap_cap = 0;
+    int64_t rmap_n = 0;                             // keyframes received so far (slot = index % rmap_cap)
+    std::vector<int32_t> rmap_root;                 // sending rank of each slot
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t ev_join = nullptr, ev_pk0 = nullptr, ev_pk1 = nullptr;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[4] = {}, ev_g4[4] = {};                // back-end milestones stage A of step N+3 waits for
@@ -98,8 +103,10 @@ struct Engine {
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
-    // device-side retracks grow a lane to at most 60 + 220 features without the host knowing which lane
-    int kmax() const { int m = rt_on ? 320 : 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
+    // device-side retracks (mode 1) grow a lane to at most 60 + 256 features without the host knowing which lane; a step in
+    // mode 2 re-detects on EVERY lane, whatever it holds: the bound of every lane then grows by the 256 the append may add
+    int rt_floor = 320;
+    int kmax() const { int m = rt_on ? rt_floor : 64; for (int k : lane_k) m = k > m ? k : m; m = (m + 63) & ~63; return m > KS ? KS : m; }
     std::vector<void *> allocs;
 };
 
@@ -149,11 +156,11 @@ __global__ __launch_bounds__(256) void g1_good_kernel(const float *__restrict__ 
                                                       const float *__restrict__ klt_next, uint8_t *__restrict__ status,
                                                       const float *__restrict__ err, float *__restrict__ good_old,
                                                       float *__restrict__ good_new, int32_t *__restrict__ good_idx,
-                                                      int32_t *__restrict__ good_n)
+                                                      int32_t *__restrict__ good_n, int kmax_launch)
 {
     __shared__ int sh[8];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int K = feat_n[b];
+    const int K = min(feat_n[b], kmax_launch);          // (the tracker ran on kmax_launch features at most)
     const int items = (KS + 255) / 256;
     const int lo = t * items, hi = min(lo + items, K);
     int c = 0;
@@ -550,16 +557,22 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         // pitch of 2024 doubles HBM saw 1.44 x the bytes written)
         r.SP = (e->W + 15) & ~15;
         ok = ok && dalloc(ctx, e, &r.S, (size_t)r.SP * e->W * R);
-        ok = ok && dalloc(ctx, e, &r.cand_rc, (size_t)R * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_val, (size_t)R * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_n, (size_t)R);
-        ok = ok && dalloc(ctx, e, &r.tasks, (size_t)R * BP_MAX_TASKS) && dalloc(ctx, e, &r.pairs, (size_t)R * (BP_MAX_PAIRS + 1));
-        ok = ok && dalloc(ctx, e, &r.order, (size_t)R * (BP_MAX_PAIRS + 1)) && dalloc(ctx, e, &r.ovbits, (size_t)R * ((BP_MAX_PAIRS + 31) / 32 + 1));
-        ok = ok && dalloc(ctx, e, &r.bigtab, (size_t)R * 2 * 131072);
-        ok = ok && dalloc(ctx, e, &r.kp, (size_t)R * BP_MAX_PTS * 3) && dalloc(ctx, e, &r.kp_n, (size_t)R) && dalloc(ctx, e, &r.slot_flags, (size_t)R);
-        ok = ok && dalloc(ctx, e, &r.ssc_work, (size_t)R * 4 * BP_MAX_PTS) && dalloc(ctx, e, &r.sel, (size_t)R * BP_MAX_PTS) && dalloc(ctx, e, &r.sel_n, (size_t)R);
+        // candidate lists and bookkeeping tables per DETECTION (0.9 MB each): K4-K7 run once per step over all of them
+        const size_t D = (size_t)B;
+        ok = ok && dalloc(ctx, e, &r.cand_rc, D * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_val, D * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_n, D);
+        ok = ok && dalloc(ctx, e, &r.tasks, D * BP_MAX_TASKS) && dalloc(ctx, e, &r.pairs, D * (BP_MAX_PAIRS + 1));
+        ok = ok && dalloc(ctx, e, &r.order, D * (BP_MAX_PAIRS + 1)) && dalloc(ctx, e, &r.ovbits, D * ((BP_MAX_PAIRS + 31) / 32 + 1));
+        ok = ok && dalloc(ctx, e, &r.bigtab, D * 2 * 131072);
+        ok = ok && dalloc(ctx, e, &r.kp, D * BP_MAX_PTS * 3) && dalloc(ctx, e, &r.kp_n, D) && dalloc(ctx, e, &r.slot_flags, D);
+        ok = ok && dalloc(ctx, e, &r.ssc_work, D * 4 * BP_MAX_PTS) && dalloc(ctx, e, &r.sel, D * BP_MAX_PTS) && dalloc(ctx, e, &r.sel_n, D);
     }
     if (!ok) { roam_engine_destroy(ctx); return ROAM_E_HIP; }
     if (e->rt_on) {
-        HIP_TRY(ctx, retrack_init());
+        if (hipError_t er = retrack_init(); er != hipSuccess) {
+            ROAM_SET_ERR(ctx, "retrack_init failed: %s", hipGetErrorString(er));
+            roam_engine_destroy(ctx);
+            return ROAM_E_HIP;
+        }
         RtArgs &r = e->rt;
         r.pool = e->pool; r.map = e->warp_map; r.feat = e->feat; r.feat_n = e->feat_n; r.vel = e->vel; r.kf_und = e->kf_und; r.res = nullptr;
     }
@@ -619,11 +632,21 @@ int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t
 {
     ENGINE();
     ARG_CHECK(ctx, host_records && n >= 1 && pool_idx0 >= 0 && pool_idx0 + n <= e->cfg.pool_scans && (host_stride == 0 || host_stride >= (int64_t)e->rec_bytes));
+    // the copy kernel dereferences the records on the GPU: they must live in pinned (or registered) host memory - a pageable
+    // buffer would fault on the device and abort the process, so it is refused here
+    hipPointerAttribute_t at;
+    const hipError_t pa = hipPointerGetAttributes(&at, host_records);
+    if (pa != hipSuccess || (at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeDevice)) {
+        (void)hipGetLastError();
+        ROAM_SET_ERR(ctx, "upload_scans_async: host_records is not pinned host memory (hipHostMalloc / hipHostRegister / roam_host_alloc)");
+        return ROAM_E_ARG;
+    }
+    const uint8_t *dev_alias = at.devicePointer ? static_cast<const uint8_t *>(at.devicePointer) : host_records;
     // only the bytes the path reads cross PCIe: metadata + the clipped payload of every row (2 036 of 3 779 bytes for the
     // Oxford record at the 87.5 m clip).  A copy KERNEL on the copy stream reads the pinned host memory directly (it is
     // device-visible) with 16-byte loads - hipMemcpy2DAsync moves such rows one by one (270 scan pairs/s measured)
     const int width = e->cfg.payload_off + e->cfg.clip;
-    hipLaunchKernelGGL(ingest_rows_kernel, dim3((e->cfg.rows + 3) / 4, n), dim3(256), 0, ctx->stream3, host_records, host_stride,
+    hipLaunchKernelGGL(ingest_rows_kernel, dim3((e->cfg.rows + 3) / 4, n), dim3(256), 0, ctx->stream3, dev_alias, host_stride,
                        e->pool + (size_t)pool_idx0 * e->rec_bytes, (int64_t)e->rec_bytes, e->cfg.rows, e->cfg.stride, width);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_up, ctx->stream3));
@@ -799,13 +822,13 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
                             int32_t cap_pts, int32_t *peaks, int64_t peaks_cap)
 {
     ENGINE();
-    ARG_CHECK(ctx, hdr_out && lane >= 0 && cap_pts >= 0 && peaks_cap >= 0);
+    // (every rank validates the lane BEFORE the collective: a root that bailed out alone would leave the others in ncclBroadcast)
+    ARG_CHECK(ctx, hdr_out && lane >= 0 && lane < e->B && cap_pts >= 0 && peaks_cap >= 0);
     static_assert(sizeof(roam_keyframe_hdr) == KFB_HDR, "header layout");
     const size_t total = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
     if (!e->kfb && !dalloc(ctx, e, &e->kfb, total)) return ROAM_E_HIP;
     hipStream_t st = ctx->stream;
     if (roam_comm_rank(ctx) == root) {
-        ARG_CHECK(ctx, lane < e->B);
         hipLaunchKernelGGL(kf_pack_kernel, dim3(16), dim3(256), 0, st, e->kfb, lane, e->kf_pose, e->kf_vel, e->feat_n, e->kf_scan,
                            e->kf_und, e->peaks_n[e->pk], e->peaks_out[e->pk], e->cfg.peaks_cap);
         HIP_TRY(ctx, hipGetLastError());
@@ -821,6 +844,15 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
         rc = roam_comm_bcast_bytes(ctx, e->kfb + KFB_PEAKS_OFF, (size_t)P * 8, root);
         if (rc != ROAM_OK) return rc;
     }
+    if (e->rmap_cap > 0) {
+        // Map.addKeyframe on this rank: the payload stays in HBM (device-to-device), header + features, then the peaks
+        const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
+        uint8_t *dst = e->rmap + (size_t)(e->rmap_n % e->rmap_cap) * slot_bytes;
+        HIP_TRY(ctx, hipMemcpyAsync(dst, e->kfb, KFB_HDR + sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(dst + KFB_PEAKS_OFF, e->kfb + KFB_PEAKS_OFF, (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+        e->rmap_root[e->rmap_n % e->rmap_cap] = root;
+        e->rmap_n++;
+    }
     if (locals_xy) {
         if (n > cap_pts) { ROAM_SET_ERR(ctx, "bcast_keyframe: %d features, capacity %d", n, cap_pts); return ROAM_E_CAPACITY; }
         if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(locals_xy, e->kfb + KFB_LOCALS_OFF, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -830,6 +862,97 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
         if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(peaks, e->kfb + KFB_PEAKS_OFF, sizeof(int32_t) * 2 * (size_t)P, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ROAM_OK;
+}
+
+int32_t roam_remote_map_reserve(roam_ctx *ctx, int32_t keyframes)
+{
+    ENGINE();
+    ARG_CHECK(ctx, keyframes > 0 && keyframes <= 65536);
+    if (e->rmap_cap > 0) { ROAM_SET_ERR(ctx, "engine: the remote map is already reserved (%d keyframes)", e->rmap_cap); return ROAM_E_STATE; }
+    const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
+    if (!dalloc(ctx, e, &e->rmap, slot_bytes * (size_t)keyframes)) return ROAM_E_HIP;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    e->rmap_root.assign((size_t)keyframes, -1);
+    e->rmap_cap = keyframes;
+    return ROAM_OK;
+}
+
+int32_t roam_remote_map_count(roam_ctx *ctx, int64_t *received, int32_t *resident)
+{
+    ENGINE();
+    ARG_CHECK(ctx, received && resident);
+    *received = e->rmap_n;
+    *resident = (int32_t)std::min<int64_t>(e->rmap_n, e->rmap_cap);
+    return ROAM_OK;
+}
+
+int32_t roam_remote_map_get(roam_ctx *ctx, int32_t index, roam_keyframe_hdr *hdr_out, int32_t *root_out, double *locals_xy,
+                            int32_t cap_pts, int32_t *peaks, int64_t peaks_cap)
+{
+    ENGINE();
+    const int resident = (int)std::min<int64_t>(e->rmap_n, e->rmap_cap);
+    ARG_CHECK(ctx, hdr_out && index >= 0 && index < resident && cap_pts >= 0 && peaks_cap >= 0);
+    // index 0 = the oldest keyframe still resident
+    const int64_t abs_i = e->rmap_n - resident + index;
+    const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
+    const uint8_t *src = e->rmap + (size_t)(abs_i % e->rmap_cap) * slot_bytes;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(hdr_out, src, sizeof(roam_keyframe_hdr), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (root_out) *root_out = e->rmap_root[abs_i % e->rmap_cap];
+    const int n = hdr_out->n_features, P = hdr_out->n_peaks;
+    if (locals_xy) {
+        if (n > cap_pts) { ROAM_SET_ERR(ctx, "remote_map_get: %d features, capacity %d", n, cap_pts); return ROAM_E_CAPACITY; }
+        if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(locals_xy, src + KFB_LOCALS_OFF, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, st));
+    }
+    if (peaks) {
+        if (P > peaks_cap) { ROAM_SET_ERR(ctx, "remote_map_get: %d peaks, capacity %lld", P, (long long)peaks_cap); return ROAM_E_CAPACITY; }
+        if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(peaks, src + KFB_PEAKS_OFF, sizeof(int32_t) * 2 * (size_t)P, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ROAM_OK;
+}
+
+// batched roam_engine_init_lane_detect for lanes lane0 .. lane0 + n - 1: one warp / pyramid launch over the n lanes and ONE
+// detection pass (chunks of `retrack_slots`) instead of n single-lane passes of 2.4 ms each (4096 lanes: 10 s -> 0.3 s)
+int32_t roam_engine_init_lanes_detect(roam_ctx *ctx, int32_t lane0, int32_t n, const int32_t *pool_idx, const double *poses3)
+{
+    ENGINE();
+    ARG_CHECK(ctx, n >= 1 && lane0 >= 0 && lane0 + n <= e->B && pool_idx && poses3);
+    if (!e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
+    for (int i = 0; i < n; i++) ARG_CHECK(ctx, pool_idx[i] >= 0 && pool_idx[i] < e->cfg.pool_scans);
+    if (e->map_cap > 0) {                                   // the keyframe map freezes the replaced keyframes lane by lane
+        for (int i = 0; i < n; i++) {
+            const int32_t rc = roam_engine_init_lane_detect(ctx, lane0 + i, pool_idx[i], poses3 + 3 * (size_t)i);
+            if (rc != ROAM_OK) return rc;
+        }
+        return ROAM_OK;
+    }
+    hipStream_t st = ctx->stream;
+    if (e->uploads_pending) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_up, 0));
+    std::vector<int32_t> lanes((size_t)n);
+    for (int i = 0; i < n; i++) lanes[i] = lane0 + i;
+    HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_n, &n, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_lane, lanes.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_scan, pool_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    // previous-image pyramids from the pool scans (lane i of the launch reads record rt_scan[i])
+    uint8_t *pyr = e->pyr[e->cur] + (size_t)lane0 * e->pd.lane_stride;
+    HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->rt.rt_scan), n, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride));
+    HIP_TRY(ctx, launch_build_pyramid(st, pyr, e->pd, n));
+    // pose, zero velocity, empty feature set, keyframe at the pose created on the scan (set_features_impl with K = 0)
+    HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane0, poses3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(e->kf_pose + 3 * (size_t)lane0, poses3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(e->vel + 3 * (size_t)lane0, 0, sizeof(double) * 3 * (size_t)n, st));
+    HIP_TRY(ctx, hipMemsetAsync(e->kf_vel + 3 * (size_t)lane0, 0, sizeof(double) * 3 * (size_t)n, st));
+    HIP_TRY(ctx, hipMemsetAsync(e->feat_n + lane0, 0, sizeof(int32_t) * (size_t)n, st));
+    HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->kf_live + lane0), 1, (size_t)n, st));
+    HIP_TRY(ctx, hipMemcpyAsync(e->kf_scan + lane0, pool_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    // first-frame appendNewFeatures(prevImgCart, empty) (RawROAMSystem.py:150) for all n lanes
+    e->rt.res = nullptr;
+    HIP_TRY(ctx, launch_retrack(st, e->rt, n));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < n; i++) e->lane_k[lane0 + i] = 320;
     return ROAM_OK;
 }
 
@@ -897,7 +1020,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KM, KS, B, e->klt_next, e->klt_status, e->klt_err));
     HIP_TRY(ctx, hipEventRecord(e->ev_klt[k4], st));
     hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,
-                       e->good_old, e->good_new, e->good_idx, e->good_n);
+                       e->good_old, e->good_new, e->good_idx, e->good_n, KM);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_GRAPH], st));
     if (c.reject_outliers) {
@@ -937,6 +1060,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         e->rt.res = res_slot;
         HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
         HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->rt_ev[e->nstep & 63]));
+        if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }
     e->rt_ev_ok[e->nstep & 63] = e->rt_on && e->rt_mode;
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));

@@ -20,9 +20,10 @@ struct RtArgs {
     roam_lane_result *res;          // result records of the step being amended (may be null)
     // flagged lanes (device-built): rt_n lanes, lane / pool scan of each
     int32_t *rt_n, *rt_lane, *rt_scan;
-    // per-slot scratch (slots entries each)
+    // per-slot scratch (slots entries): the image-scale kernels work on chunks of `slots` detections
     double *S;                      // W rows x SP float64: integral image, rows padded to whole 128-byte lines
     int SP;                         // row pitch of S in elements (a multiple of 16, >= W)
+    // per-detection scratch (one entry per lane: the bookkeeping kernels run once over all detections of a step)
     uint32_t *cand_rc;              // BP_MAX_PTS: row << 16 | col << 2 | layer (appended by the determinant kernel, sorted by rt_emit_kernel)
     double *cand_val;               // BP_MAX_PTS
     int32_t *cand_n;                // maxima found (may exceed BP_MAX_PTS: RT_F_CAND_OVERFLOW, the kept subset is then arbitrary)

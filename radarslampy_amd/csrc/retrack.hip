@@ -18,8 +18,9 @@
 //   K6 ssc_batch         ANMS.ssc (ssc.hip)
 //   K7 rt_append         [x, y] flip, vstack + drop exact duplicates keeping the first (getFeatures.py:109-112), keyframe
 //                        refresh (Mapping.py:59-66 with the frame's velocity), feature count
-// Slots are processed in chunks of `slots` lanes (scratch: 33 MB per slot); every kernel exits at once for slots beyond
-// the number of flagged lanes, which only the device knows.
+// The image-scale kernels (K1-K3) run in chunks of `slots` detections (scratch: a 33 MB integral image per slot); K3 appends to
+// per-DETECTION candidate lists, and K4-K7 run once over all detections of the step.  Every kernel exits at once for
+// detections beyond the number of flagged lanes, which only the device knows.
 #include "roam_internal.h"
 #include "doh_common.h"
 #include "blobprune.h"
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
 #pragma unroll
             for (int dc = -1; dc <= 1; dc++) { const double u = m2at(buf, rr2 + dr, dc); mx = u > mx ? u : mx; }
         const uint32_t bits = ((v0 > thr && !(mx > v0)) ? 1u : 0u) | ((v1 > thr && !(mx > v1)) ? 2u : 0u);
-        if (bits) rt_push_maxima(a, ls, r, c, bits, v0, v1);
+        if (bits) rt_push_maxima(a, first + ls, r, c, bits, v0, v1);
     };
     // maxima of step pt (rows 0 .. SD_T - 2) and of the last row of the step before it; everything they need is in step pt's buffer
     auto maxima = [&](int pt, int buf) {
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
     const int b = a.rt_lane[slot], t = threadIdx.x;
     float *feat = a.feat + (int64_t)b * KS * 2;
     const int n_old = min(a.feat_n[b], KS);
-    const int n_sel = min(a.sel_n[ls], 256);
+    const int n_sel = min(a.sel_n[ls], 256);                                  // (ANMS returns at most 220; more would be dropped: flagged below)
     const double *kp = a.kp + (int64_t)ls * BP_MAX_PTS * 3;
     const int32_t *sel = a.sel + (int64_t)ls * BP_MAX_PTS;
     // vstack((old, fliplr(new[:, :2])))  (getFeatures.py:101-109)
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
     if (t == 0) {
         a.feat_n[b] = m;
         if (a.res) {
-            a.res[b].flags |= 8 | (a.slot_flags[ls] << 8) | (total > KS ? (RT_F_FEAT_OVERFLOW << 8) : 0);
+            a.res[b].flags |= 8 | (a.slot_flags[ls] << 8) | ((total > KS || a.sel_n[ls] > 256) ? (RT_F_FEAT_OVERFLOW << 8) : 0);
             a.res[b].n_after_retrack = m;
         }
     }
@@ -1046,10 +1047,13 @@ static hipError_t launch_det(hipStream_t st, const RtArgs &a, int first, int P)
 hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace)
 {
     const int W = a.W, R = a.slots;
+    // image-scale kernels chunk by chunk (the float64 integral images of `slots` detections are resident at once); the
+    // candidate lists are per DETECTION, so the lane-serial bookkeeping runs once over all of them afterwards (round 2 ran it per
+    // chunk: 1.4-2.7 ms of a near-idle GPU each time)
+    hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)B, st);
+    if (e != hipSuccess) return e;
     for (int first = 0; first < B; first += R) {
         const int P = min(R, B - first);
-        hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
-        if (e != hipSuccess) return e;
         const bool tr = trace && first == 0;
         if (tr && (e = hipEventRecord(trace[0], st)) != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
@@ -1058,15 +1062,13 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if (tr && (e = hipEventRecord(trace[1], st)) != hipSuccess) return e;
         if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(trace[2], st)) != hipSuccess) return e;
-        hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, first);
-        hipLaunchKernelGGL(rt_blobs_kernel, dim3(P), dim3(64), 0, st, a, first);
-        e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, P, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, first);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(rt_append_kernel, dim3(P), dim3(256), 0, st, a, first);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
     }
-    return hipSuccess;
+    hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
+    hipLaunchKernelGGL(rt_blobs_kernel, dim3(B), dim3(64), 0, st, a, 0);
+    e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rt_append_kernel, dim3(B), dim3(256), 0, st, a, 0);
+    return hipGetLastError();
 }
 
 hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, int force_all, const RtArgs &a)
@@ -1090,10 +1092,4 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
         return launch_det(st, a, 0, P);
     }
     return hipGetLastError();
-}
-
-size_t retrack_slot_bytes(int W)
-{
-    return (size_t)W * W * (sizeof(double) + 1) + sizeof(int32_t) * (W + 1) + BP_MAX_PTS * (sizeof(uint32_t) + sizeof(double) + 3 * sizeof(double) + 5 * sizeof(int32_t))
-           + BP_MAX_TASKS * sizeof(BpTask) + (BP_MAX_PAIRS + 1) * (sizeof(uint32_t) + sizeof(uint16_t)) + 2 * 131072 * sizeof(uint16_t);
 }

@@ -60,6 +60,33 @@ class Engine:
         pose = np.ascontiguousarray(pose, np.float64)
         self.ctx.check(self.lib.roam_engine_init_lane_detect(self.ctx.h, int(lane), int(pool_idx), _ffi._ptr(pose)))
 
+    def init_lanes_detect(self, lane0: int, pool_idx, poses):
+        """init_lane_detect for the lanes lane0 .. lane0 + n - 1 in ONE device pass (pool_idx (n,), poses (n, 3))"""
+        pool_idx = np.ascontiguousarray(pool_idx, np.int32).ravel()
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 3)
+        assert len(pool_idx) == len(poses)
+        self.ctx.check(self.lib.roam_engine_init_lanes_detect(self.ctx.h, int(lane0), len(pool_idx), _ffi._ptr(pool_idx), _ffi._ptr(poses)))
+
+    # ---- 8e consumer: the global map of received keyframes (Mapping.Map.addKeyframe on every rank)
+    def remote_map_reserve(self, keyframes: int = 64):
+        self.ctx.check(self.lib.roam_remote_map_reserve(self.ctx.h, int(keyframes)))
+
+    def remote_map_count(self):
+        """(keyframes received so far, keyframes resident in the ring)"""
+        rec, res = C.c_int64(0), C.c_int32(0)
+        self.ctx.check(self.lib.roam_remote_map_count(self.ctx.h, C.byref(rec), C.byref(res)))
+        return rec.value, res.value
+
+    def remote_map_get(self, index: int) -> dict:
+        """received keyframe `index` (0 = the oldest resident): the dict RcclComm.bcast_keyframe returns + the sending rank"""
+        hdr, root = _ffi.KeyframeHdr(), C.c_int32(-1)
+        loc = np.empty((_ffi.MAX_FEATURES, 2), np.float64)
+        pk = np.empty((self.cfg.peaks_cap, 2), np.int32)
+        self.ctx.check(self.lib.roam_remote_map_get(self.ctx.h, int(index), C.byref(hdr), C.byref(root), _ffi._ptr(loc), loc.shape[0],
+                                                    _ffi._ptr(pk), pk.shape[0]))
+        return dict(pose=np.array(hdr.pose[:]), velocity=np.array(hdr.velocity[:]), prunedUndistortedLocals=loc[:hdr.n_features].copy(),
+                    peaks=pk[:hdr.n_peaks].copy(), scan=hdr.scan, lane=hdr.lane, root=root.value)
+
     def set_features(self, lane: int, pts: np.ndarray):
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
         self.ctx.check(self.lib.roam_engine_set_features(self.ctx.h, int(lane), _ffi._ptr(pts), pts.shape[0]))

@@ -320,6 +320,8 @@ def test_rccl_keyframe_broadcast_world1(sequences):
         assert comm.info() == (0, 1)
         assert comm.allreduce_max(0.125) == 0.125
         comm.barrier()
+        eng.remote_map_reserve(3)                        # the consumer: Map.addKeyframe on every rank, in HBM
+        sent = []
         for lane in (0, B - 1):
             got = comm.bcast_keyframe(eng, 0, lane)
             want = eng.live_keyframe(lane)
@@ -327,7 +329,38 @@ def test_rccl_keyframe_broadcast_world1(sequences):
             for k in ("pose", "velocity", "prunedUndistortedLocals", "peaks"):
                 assert np.array_equal(got[k], want[k]), k
             assert len(got["peaks"]) > 1000 and len(got["prunedUndistortedLocals"]) > 20
+            sent.append(got)
+        for lane in (0, 0):
+            sent.append(comm.bcast_keyframe(eng, 0, lane))
+        # four keyframes went through a ring of three: the oldest is gone, the others are byte for byte what was broadcast
+        assert eng.remote_map_count() == (4, 3)
+        for i in range(3):
+            kf = eng.remote_map_get(i)
+            assert kf["root"] == 0 and kf["lane"] == sent[1 + i]["lane"] and kf["scan"] == sent[1 + i]["scan"]
+            for k in ("pose", "velocity", "prunedUndistortedLocals", "peaks"):
+                assert np.array_equal(kf[k], sent[1 + i][k]), (i, k)
+        with pytest.raises(_ffi.RoamError):
+            comm.bcast_keyframe(eng, 0, B)                # a lane that does not exist is refused before any collective starts
     finally:
         comm.close()
+    eng.close()
+    ctx.close()
+
+
+def test_pageable_host_memory_is_refused_by_the_async_upload(sequences):
+    """roam_engine_upload_scans_async reads the records from the GPU: a pageable numpy buffer must come back as an argument
+    error, not as a device fault"""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    ctx = _ffi.Context(0)
+    eng = Engine(1, 2, ctx=ctx)
+    rec = np.ascontiguousarray(sequences[0][0][0])
+    with pytest.raises(_ffi.RoamError) as ei:
+        eng.upload_scans_async(0, rec, n=1)
+    assert ei.value.code == _ffi.ROAM_E_ARG and "pinned" in str(ei.value)
+    pinned = ctx.host_alloc(rec.shape)
+    pinned[...] = rec
+    eng.upload_scans_async(0, pinned, n=1)
+    eng.synchronize()
     eng.close()
     ctx.close()

@@ -300,3 +300,74 @@ def test_detection_on_image_sizes_that_do_not_fill_the_strips(clip):
         assert np.array_equal(got, want), (clip, b, len(got), len(want))
     eng.close()
     ctx.close()
+
+
+def test_batched_first_detection_equals_lane_by_lane():
+    """roam_engine_init_lanes_detect (one warp / pyramid / detection pass over n lanes, 5 lanes through 2 scratch slots) leaves
+    exactly the state n calls of roam_engine_init_lane_detect leave: features, keyframes, and the next step's records"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, _ = synth.make_sequence(23, 3, n_movers=8, distortion=True)
+    ctx = _ffi.Context(0)
+    B = 5
+    idx = [0, 1, 0, 1, 1]
+    p0 = np.array([poses[i] for i in idx])
+
+    def run(batched):
+        eng = Engine(B, 3, ctx=ctx, retrack_on_device=True, retrack_slots=2)
+        for t in range(3):
+            eng.upload_scan(t, recs[t])
+        if batched:
+            eng.init_lanes_detect(1, idx[1:4], p0[1:4])          # a range in the middle, then the rest lane by lane
+            eng.init_lane_detect(0, idx[0], p0[0])
+            eng.init_lanes_detect(4, idx[4:], p0[4:])
+        else:
+            for b in range(B):
+                eng.init_lane_detect(b, idx[b], p0[b])
+        feats = [eng.lane_features(b) for b in range(B)]
+        kfs = [eng.live_keyframe(b) for b in range(B)]
+        eng.step([i + 1 for i in idx])
+        out = eng.results_array().tobytes()
+        eng.close()
+        return feats, kfs, out
+
+    fa, ka, ra = run(False)
+    fb, kb, rb = run(True)
+    for b in range(B):
+        assert len(fa[b]) >= 180 and np.array_equal(fa[b], fb[b]), b
+        for k in ("pose", "velocity", "prunedUndistortedLocals"):
+            assert np.array_equal(ka[b][k], kb[b][k]), (b, k)
+        assert ka[b]["scan"] == kb[b]["scan"]
+    assert ra == rb
+    ctx.close()
+
+
+def test_lanes_that_grow_past_320_features_are_tracked_in_full():
+    """a forced detection (set_retrack(2)) on lanes that already hold ~200 features takes them past the 320 the host used to
+    assume for device-side retracks: the next step must track ALL of them (dead reckoning, so that the pose depends on the
+    tracker alone) - counts and pose equal the oracle's on the same feature set"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, _ = synth.make_sequence(29, 4, n_movers=6)
+    ctx = _ffi.Context(0)
+    eng = Engine(2, 4, ctx=ctx, motion_distortion=False, retrack_on_device=True)
+    for t in range(4):
+        eng.upload_scan(t, recs[t])
+    eng.init_lanes_detect(0, [0, 0], np.array([poses[0], poses[0]]))
+    eng.set_retrack(2)
+    eng.step([1, 1])                                          # ~150 inliers + up to 220 new blobs per lane
+    eng.set_retrack(1)
+    res1 = eng.results()
+    feats = [eng.lane_features(b) for b in range(2)]
+    assert min(len(f) for f in feats) > 320, [len(f) for f in feats]
+    eng.step([2, 2])
+    res2 = eng.results()
+    for b in range(2):
+        pipe = oracle.OdometryPipeline(recs[1], feats[b], res1[b]["pose"], motion_distortion=False, detect=_detect)
+        want = pipe.step(recs[2])
+        got = res2[b]
+        assert got["n_tracked"] == len(feats[b]) == want["n_tracked"], b
+        assert got["n_good"] == want["n_good"] and got["n_inliers"] == want["n_inliers"], (b, got["n_good"], want["n_good"])
+        _same_pose(got, want, b)
+    eng.close()
+    ctx.close()
