@@ -13,7 +13,9 @@ Launch either way:
                                                                RANK / LOCAL_RANK / WORLD_SIZE variables are used)
 Neither path imports torch: barrier and max-over-ranks time go through RCCL (roam_comm_*), the ncclUniqueId through a
 rendezvous directory.  Rank 0 prints ONE JSON line with the `roofline` and `cpu_baseline` objects of DESIGN.md §5.
-`--dry-engine` swaps the GPU engine for a stub (CPU test of this launcher; never a measurement)."""
+`--dry-engine` swaps the GPU engine for a stub (CPU test of this launcher; never a measurement).
+`--stream` measures ONE sequence instead (BASELINE configs 3 / 4 as the reference runs them): engine-only scan pairs/s of a single
+lane fed from a pinned ring, and its per-pair latency when every pose is awaited before the next frame is stepped."""
 import argparse
 import json
 import os
@@ -38,7 +40,11 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=None, help="independent sequences resident per GPU (default 4096; 1024 with --h2d)")
     ap.add_argument("--frames", type=int, default=7, help="frames per synthetic sequence (played ping-pong)")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic sequences generated per rank")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic sequences generated per rank")
+    ap.add_argument("--render-procs", type=int, default=0, help="processes rendering the synthetic sequences (0 = min(distinct, cores / 2))")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N launcher: wall-clock limit for the whole run, seconds")
+    ap.add_argument("--stream", action="store_true", help="single-sequence mode: one lane, pinned ring, result ring (configs 3 / 4)")
+    ap.add_argument("--stream-frames", type=int, default=240, help="frames of the --stream sequence")
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle, 1 core (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the N-core CPU leg (-1 = half the logical cores, 0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
@@ -56,21 +62,97 @@ def parse_args(argv=None):
 
 
 # ------------------------------------------------------------------------------------------------ launcher
+def visible_gpu_count():
+    """GPUs of this node WITHOUT any HIP call (the launcher must stay GPU-free: its children are fresh processes): KFD topology
+    nodes that have SIMDs.  None when the topology is not readable (no KFD: a CPU box)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(root):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(root, d, "properties")) if len(l.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except OSError:
+        return None
+
+
 def spawn_ranks(args, argv):
-    """--gpus N without a launcher: start N rank processes BEFORE anything touches HIP (fresh children, never an exec of
-    a process that initialised the GPU), pass rank / device through the environment, relay rank 0's JSON line."""
+    """--gpus N without a launcher: start N rank processes BEFORE anything touches HIP (fresh children, never an exec of a
+    process that initialised the GPU), pass rank / device through the environment, watch ALL of them, relay rank 0's JSON line.
+    A rank that exits non-zero (or the wall-clock limit) ends the run within seconds: the others are told through the rendezvous
+    directory (their watchdog threads leave even a blocked RCCL collective), then terminated, and the exit code is non-zero."""
+    from radarslampy_amd import distributed as D
+    if not args.dry_engine:
+        have = visible_gpu_count()
+        if have is not None and have < args.gpus:
+            sys.stderr.write(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s)\n")
+            return 2
     rdv = tempfile.mkdtemp(prefix="roam_rdv_")
-    procs = []
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), ROAM_RDV_DIR=rdv,
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+        out, err = open(os.path.join(rdv, f"out.{r}"), "w+"), open(os.path.join(rdv, f"err.{r}"), "w+")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out, stderr=err, text=True))
+    t0, bad = time.monotonic(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if failed:
+            bad = f"rank(s) {failed} exited with {[codes[r] for r in failed]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > args.launch_timeout:
+            bad = f"wall-clock limit of {args.launch_timeout:.0f} s reached"
+            failed = [r for r, c in enumerate(codes) if c is None]
+            break
+        time.sleep(0.05)
+    if bad:
+        for r in failed:
+            D.FileRendezvous(rdv, r, args.gpus).mark_failed(bad)            # the survivors' watchdogs see it and leave
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 3.0:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 3.0:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(f"[bench] {bad}; rank logs kept in {rdv}\n")
+        for r, (out, err) in enumerate(logs):
+            err.seek(0)
+            tail = err.read()[-1500:]
+            if tail.strip():
+                sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{tail}\n")
+        return 1
+    for r, (out, err) in enumerate(logs):
+        err.seek(0)
+        sys.stderr.write(err.read())
+    logs[0][0].seek(0)
+    sys.stdout.write(logs[0][0].read())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    for out, err in logs:
+        out.close(); err.close()
+    try:                                                     # (rank 0 removes the directory itself when the communicator closes)
+        for f in os.listdir(rdv):
+            try:
+                os.unlink(os.path.join(rdv, f))
+            except OSError:
+                pass
+        os.rmdir(rdv)
+    except OSError:
+        pass
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ engines
@@ -82,10 +164,16 @@ class DryEngine:
 
     def __init__(self, lanes, rank):
         self.lanes, self.rank, self.n, self.cfg = lanes, rank, 0, self._Cfg()
+        self.remote_map = []
+
+    def remote_map_add(self, kf):
+        self.remote_map.append(kf)
 
     def step(self, idx):
         assert len(idx) == self.lanes
         self.n += 1
+        if os.environ.get("ROAM_DRY_FAIL_RANK") == str(self.rank) and self.n == 2:
+            raise RuntimeError("injected failure (ROAM_DRY_FAIL_RANK)")        # CPU test of the launcher's failure handling
         time.sleep(0.002 * (self.rank + 1))
 
     def synchronize(self):
@@ -103,13 +191,16 @@ class DryEngine:
         pass
 
 
+WORK_RETRACK = dict(n_static=460, n_movers=120, scintillation=0.6)
+WORK_STEADY = dict(n_static=460, n_movers=24)
+
+
 def cpu_worker(job):
     """one independent oracle pipeline (N-core leg of the CPU baseline); returns (pairs, seconds)"""
     seed, frames, pairs, md, retrack = job
     import oracle
     from radarslampy_amd import synth
-    work = dict(n_static=460, n_movers=120, scintillation=0.6) if retrack else dict(n_static=460, n_movers=24)
-    recs, poses, feat = synth.make_sequence(seed, frames, distortion=md, **work)
+    recs, poses, feat = synth.make_sequence(seed, frames, distortion=md, **(WORK_RETRACK if retrack else WORK_STEADY))
     cyc = list(range(1, frames)) + list(range(frames - 2, -1, -1))
     det = (lambda cart: oracle.getFeatures(cart)[0]) if retrack else None
     if retrack:
@@ -121,14 +212,49 @@ def cpu_worker(job):
     return pairs, time.perf_counter() - t0
 
 
+def _render_sequence(job):
+    seed, frames, md, work = job
+    from radarslampy_amd import synth
+    return synth.make_sequence(seed, frames, distortion=md, **work)
+
+
+def render_sequences(seeds, frames, md, work, procs):
+    """the rank's distinct synthetic sequences, rendered on host cores in parallel (input generation, before the GPU is touched)"""
+    jobs = [(s, frames, md, work) for s in seeds]
+    procs = procs if procs > 0 else max(1, min(len(jobs), (os.cpu_count() or 2) // 2))
+    if procs == 1 or len(jobs) == 1:
+        return [_render_sequence(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(procs) as pool:
+        return pool.map(_render_sequence, jobs)
+
+
+# a lane keeps this fraction of its first detection: lanes enter the timed loop at different points of their retrack cycle
+# (they would otherwise all run out of features in the same steps: every lane detects ~200 features at set-up and loses
+# the same ~26 % per pair)
+AGE_FRACTIONS = (1.0, 0.86, 0.74, 0.64, 0.55, 0.47, 0.40, 0.34)
+
+
 def run_rank(args):
     from radarslampy_amd import distributed as D
     rank, local_rank, world = D.rank_env()
     if world != args.gpus:
         sys.stderr.write(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size\n")
+    rdv = D.FileRendezvous(D.rendezvous_dir(), rank, world) if (world > 1 or args.force_comm) else None
+    if rdv is not None and world > 1:
+        rdv.watchdog()                                   # another rank's failure ends this process too
+    try:
+        _run_rank(args, D, rank, local_rank, world, rdv)
+    except BaseException as ex:                          # noqa: BLE001
+        if rdv is not None:
+            rdv.mark_failed(repr(ex))
+        raise
+
+
+def _run_rank(args, D, rank, local_rank, world, rdv):
     B, T, Dn_ = args.lanes, args.frames, max(1, min(args.distinct, args.lanes))
     cyc = list(range(1, T)) + list(range(T - 2, -1, -1))           # ping-pong frame schedule 1,2,..,T-1,T-2,..,0,1,..
-    rdv = D.FileRendezvous(D.rendezvous_dir(), rank, world) if (world > 1 or args.force_comm) else None
+    retracks_per_step = []
 
     if args.dry_engine:
         eng = DryEngine(B, rank)
@@ -137,20 +263,28 @@ def run_rank(args):
         step_all = lambda i: eng.step(np.zeros(B, np.int32))       # noqa: E731
         seqs = None
     else:
-        from radarslampy_amd import _ffi, synth
+        # workload: reflector world with 120 movers and scan-to-scan scintillation: ~26 % of the tracked correspondences are
+        # rejected per pair (the paper reports 28 %) and features run out every 3-5 pairs (real `tiny` scans: every 2-3), so
+        # the feature re-detection (DoH + ANMS) is part of the timed loop at the cadence the data dictates
+        WORK = WORK_STEADY if args.no_retrack else WORK_RETRACK
+        seqs = render_sequences([1000 * rank + 17 * d + 5 for d in range(Dn_)], T, not args.no_md, WORK, args.render_procs)
+        from radarslampy_amd import _ffi
         from radarslampy_amd.engine import Engine
         ctx = _ffi.Context(local_rank)
         info = ctx.device_info()
         comm = None
         if rdv:
-            # native RCCL communicator (csrc/comm.hip).  If it cannot be created on ANY rank (no librccl, IPC refused ...) every
-            # rank agrees - through the rendezvous directory - to aggregate the timing through files instead, so that a line is
+            # native RCCL communicator (csrc/comm.hip).  The ranks first agree - through the rendezvous directory, before anyone
+            # enters the collective ncclCommInitRank, which has no timeout - that librccl can be bound everywhere; then that the
+            # communicator came up everywhere.  Otherwise all of them aggregate the timing through files instead, so that a line is
             # still printed; "collective_backend" says which one ran
-            try:
-                comm = D.RcclComm(ctx, rdv)
-            except Exception as ex:                                     # noqa: BLE001
-                sys.stderr.write(f"[bench] rank {rank}: RCCL communicator failed ({ex}); falling back to the file communicator\n")
-            votes = rdv.gather("rccl_ok", b"1" if comm is not None else b"0")
+            votes = rdv.gather("rccl_available", b"1" if D.RcclComm.available(ctx) else b"0")
+            if all(v == b"1" for v in votes):
+                try:
+                    comm = D.RcclComm(ctx, rdv)
+                except Exception as ex:                                     # noqa: BLE001
+                    sys.stderr.write(f"[bench] rank {rank}: RCCL communicator failed ({ex}); falling back to the file communicator\n")
+                votes = rdv.gather("rccl_ok", b"1" if comm is not None else b"0")
             if any(v != b"1" for v in votes):
                 if comm is not None:
                     comm.close_native()
@@ -158,17 +292,21 @@ def run_rank(args):
         E = max(1, args.engines)
         assert B % E == 0
         BE = B // E
-        # workload: reflector world with 120 movers and scan-to-scan scintillation: ~26 % of the tracked correspondences are
-        # rejected per pair (the paper reports 28 %) and features run out every ~3 pairs (real `tiny` scans: every 2-3), so
-        # the feature re-detection (DoH + ANMS) is part of the timed loop at the cadence the data dictates
-        WORK = dict(n_static=460, n_movers=24) if args.no_retrack else dict(n_static=460, n_movers=120, scintillation=0.6)
-        seqs = [synth.make_sequence(1000 * rank + 17 * d + 5, T, distortion=not args.no_md, **WORK) for d in range(Dn_)]
         # every lane owns private copies of its T records (device-to-device replicas of the D distinct
         # sequences): identical content, distinct HBM addresses -> input reads are real HBM traffic
         ctxs = [ctx] + [_ffi.Context(local_rank) for _ in range(E - 1)]
         engs = []
         period = 2 * T - 2
         cyc_full = list(range(T)) + list(range(T - 2, 0, -1))          # ping-pong 0,1,..,T-1,T-2,..,1
+
+        def age_lanes(en, nb):
+            """thin the first detections (AGE_FRACTIONS): lane b keeps a leading share of its features, in detection order"""
+            for b in range(nb):
+                f = AGE_FRACTIONS[(b // Dn_ + b) % len(AGE_FRACTIONS)]
+                if f < 1.0:
+                    feat = en.lane_features(b)
+                    en.set_features(b, feat[:max(61, int(len(feat) * f))])
+
         for e in range(E):
             en = Engine(BE, BE * T, ctx=ctxs[e], motion_distortion=not args.no_md, retrack_on_device=not args.no_retrack,
                         retrack_slots=args.retrack_slots)
@@ -180,14 +318,16 @@ def run_rank(args):
                 for t in range(T):
                     en.copy_scan(b * T + t, (b % Dn) * T + t)
             en.synchronize()
-            # replicas of one sequence start at different frames of the cycle, so that their retracks do not coincide
+            # replicas of one sequence start at different frames of the cycle
             en.phase = np.array([0 if (args.no_retrack or args.h2d) else (b // Dn) % period for b in range(BE)])
-            for b in range(BE):
-                d, t0 = b % Dn, cyc_full[en.phase[b]]
-                if args.no_retrack:
-                    en.init_lane(b, b * T, seqs[d][2], seqs[d][1][0])
-                else:
-                    en.init_lane_detect(b, b * T + t0, seqs[d][1][t0])     # first features detected on the device (DoH + ANMS)
+            t0s = [cyc_full[en.phase[b]] for b in range(BE)]
+            if args.no_retrack:
+                for b in range(BE):
+                    en.init_lane(b, b * T, seqs[b % Dn][2], seqs[b % Dn][1][0])
+            else:
+                # first features detected on the device (DoH + ANMS), all lanes in one pass
+                en.init_lanes_detect(0, [b * T + t0s[b] for b in range(BE)], np.array([seqs[b % Dn][1][t0s[b]] for b in range(BE)]))
+                age_lanes(en, BE)
             engs.append(en)
         eng = engs[0]
         cyc_arr = np.array(cyc_full)
@@ -204,14 +344,14 @@ def run_rank(args):
                 en.close()
             eng = Engine(B, 2 * B, ctx=ctx, motion_distortion=not args.no_md, retrack_on_device=not args.no_retrack, retrack_slots=args.retrack_slots)
             engs = [eng]
-            per = B // Dn_
+            per = max(1, B // Dn_)
             # every lane's record has its own pinned source (T x B records, 1.5 MB each): the copy kernel reads host memory
             # through the GPU's caches, so a replicated source would be served from cache instead of crossing PCIe
             pinned = ctx.host_alloc((T, B, 400, 3779))
+            lane_seq = [min(b // per, Dn_ - 1) for b in range(B)]
             for t in range(T):
-                for d in range(Dn_):
-                    lo, hi = d * per, (B if d == Dn_ - 1 else (d + 1) * per)
-                    pinned[t, lo:hi] = seqs[d][0][t]
+                for b in range(B):
+                    pinned[t, b] = seqs[lane_seq[b]][0][t]
             cyc = cyc_full[1:] + cyc_full[:1]
 
             def upload(step, half):
@@ -220,12 +360,12 @@ def run_rank(args):
 
             upload(-1, 0)
             eng.synchronize()
-            for b in range(B):
-                d = min(b // per, Dn_ - 1)
-                if args.no_retrack:
-                    eng.init_lane(b, b, seqs[d][2], seqs[d][1][0])
-                else:
-                    eng.init_lane_detect(b, b, seqs[d][1][0])
+            if args.no_retrack:
+                for b in range(B):
+                    eng.init_lane(b, b, seqs[lane_seq[b]][2], seqs[lane_seq[b]][1][0])
+            else:
+                eng.init_lanes_detect(0, np.arange(B), np.array([seqs[lane_seq[b]][1][0] for b in range(B)]))
+                age_lanes(eng, B)
             upload(0, 1)
 
             def step_all(i):                                   # noqa: F811
@@ -247,15 +387,18 @@ def run_rank(args):
     def consume(step):
         if args.dry_engine or step < 0:
             return
+        tot = 0
         for en in engs:
             r = en.results_array(step)
             stat["steps"] += 1
             nrt = int(np.count_nonzero(r["flags"] & 8))
             stat["retracks"] += nrt
+            tot += nrt
             if en is engs[0]:
                 stat.setdefault("per_step", {})[step] = nrt           # lanes of engine 0 that re-detected in this step
             stat["overflow"] += int(np.count_nonzero((r["flags"] >> 8) & 15))
             stat["tracked"] += int(r["n_tracked"].sum()); stat["good"] += int(r["n_good"].sum()); stat["inliers"] += int(r["n_inliers"].sum())
+        retracks_per_step.append(tot)
 
     s = 0
     for _ in range(args.warmup):
@@ -285,16 +428,26 @@ def run_rank(args):
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
 
     # BASELINE config 5: the only exchange the path has - every rank in turn broadcasts the live keyframe of its lane 0
-    # {pose, velocity, undistorted features, polar peaks} from HBM over RCCL (reported, not part of `value`)
-    kf_ms, comm_seen = None, None
+    # {pose, velocity, undistorted features, polar peaks} from HBM over RCCL (reported, not part of `value`); every rank
+    # appends what it receives to its device-resident global map (Mapping.Map.addKeyframe, roam_remote_map_*)
+    kf_ms, comm_seen, map_seen = None, None, None
     if comm is not None:
         comm_seen = comm.info()
+        if not args.dry_engine:
+            eng.remote_map_reserve(max(8, 2 * world))
         comm.bcast_keyframe(eng, 0, 0)                                         # warm-up (channel setup)
         k0 = time.perf_counter()
         for src in range(world):
             got = comm.bcast_keyframe(eng, src, 0)
             assert got["prunedUndistortedLocals"].shape[1] == 2 and got["peaks"].shape[1] == 2 and got["lane"] == 0
         kf_ms = (time.perf_counter() - k0) * 1e3 / world
+        if args.dry_engine:
+            map_seen = [len(eng.remote_map), sorted({kf["root"] for kf in eng.remote_map})]
+        else:
+            n_rec, n_res = eng.remote_map_count()
+            last = eng.remote_map_get(n_res - 1)
+            assert last["root"] == world - 1 and np.array_equal(last["pose"], got["pose"]) and np.array_equal(last["peaks"], got["peaks"])
+            map_seen = [n_rec, sorted({eng.remote_map_get(i)["root"] for i in range(n_res)})]
 
     # steady vs retrack throughput beside the mix (after the timed region; single numbers of this rank)
     extra = {}
@@ -310,6 +463,8 @@ def run_rank(args):
         for en in engs:
             en.synchronize()
         extra["steady_pairs_per_s"] = round(B * k2 / (time.perf_counter() - t1), 1)
+        # (lanes are not re-seeded during the segment: the feature sets shrink, so the tracker does less work than in the mix)
+        extra["steady_mean_tracked"] = round(float(np.mean([en.results_array()["n_tracked"].mean() for en in engs])), 1)
         for en in engs:
             en.set_retrack(2)                                   # every lane re-detects: the cost of a retrack pair
         step_all(s); s += 1
@@ -328,24 +483,27 @@ def run_rank(args):
     if rank == 0:
         pairs = B * args.steps * world
         value = pairs / dt
+        rps = retracks_per_step[-args.steps:] if retracks_per_step else []
         out = {
             "metric": "radar scan-pairs/sec (400x3768 polar)", "value": round(value, 2), "unit": "scan-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
             "data": f"synthetic Oxford-format 400x3779 u8 records; {Dn_} distinct seeded sequences x {T} frames per rank (460 static reflectors + "
-                    + ("24 movers" if args.no_retrack else "120 movers, scan-to-scan scintillation 0.6") + f"), replicated into {B} lane-private HBM copies, ping-pong replay with staggered phases",
+                    + ("24 movers" if args.no_retrack else "120 movers, scan-to-scan scintillation 0.6") + f"), replicated into {B} lane-private HBM copies, ping-pong replay with staggered phases"
+                    + ("" if args.no_retrack else "; lanes start from device-side detections thinned to 34-100 % so that their retrack cycles are out of step"),
             "config": {"workload": "scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
                                    + ("motion-distortion LM" if not args.no_md else "dead reckoning")
                                    + (", keyframe bookkeeping; features host-seeded, no re-detection)" if args.no_retrack else
                                       ", keyframe bookkeeping, DoH + ANMS re-detection on the device whenever a lane runs out of features; every lane's pose read back every step)"),
-                       "lanes_per_gpu": B, "engines_per_gpu": len(engs), "h2d_streaming": bool(args.h2d), "frames": T,
+                       "lanes_per_gpu": B, "engines_per_gpu": len(engs), "h2d_streaming": bool(args.h2d), "frames": T, "distinct_sequences": Dn_,
                        "device": info["name"], "arch": info["arch"], "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("bench.py --gpus" if world > 1 else "single process"),
                        "collective_backend": None if comm is None else comm.backend,
-                       "comm_rank_world_seen": comm_seen,
+                       "comm_rank_world_seen": comm_seen, "global_map_keyframes_and_senders": map_seen,
                        "mean_tracked": round(stat["tracked"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 1) if stat["steps"] else round(float(np.mean([r["n_tracked"] for r in res])), 1),
                        "mean_inliers": round(stat["inliers"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 1) if stat["steps"] else round(float(np.mean([r["n_inliers"] for r in res])), 1),
                        "rejected_fraction": round(1.0 - stat["inliers"] / max(1, stat["good"]), 4) if stat["steps"] else None,
                        "retrack_fraction": round(stat["retracks"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 4) if stat["steps"] else None,
+                       "retracks_per_step": None if not rps else {"min": int(min(rps)), "mean": round(float(np.mean(rps)), 1), "max": int(max(rps))},
                        "detect_overflows": stat["overflow"],
                        "mean_lm_nfev": round(float(np.mean([r["lm_nfev"] for r in res])), 1),
                        "keyframe_broadcast_ms": None if kf_ms is None else round(kf_ms, 3)},
@@ -369,6 +527,32 @@ def run_rank(args):
         print(json.dumps(out), flush=True)
 
 
+HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: what streaming kernels reach
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def pmc_record(kname):
+    """the committed PMC measurement of a kernel (profiles/r*_pmc_traffic.json, written by profiles/pmc_traffic.py on the GPU box) -
+    used only while the kernel's SOURCE is the one that was measured (the file records the source's hash); else None"""
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            k = tj["kernels"].get(kname)
+            if not k:
+                continue
+            src = os.path.join(ROOT, "radarslampy_amd", "csrc", k.get("source_file", ""))
+            if not k.get("source_sha16") or not os.path.isfile(src) or _sha16(src) != k["source_sha16"]:
+                return None, cand + " (stale: the kernel's source changed since the PMC passes)"
+            return dict(k, units_per_launch=tj.get("units_per_launch", tj.get("lanes"))), cand
+        except Exception:                                              # noqa: BLE001
+            continue
+    return None, None
+
+
 def roofline(eng, args, B, retrack_fraction, live_all):
     """roofline of the dominant HBM-streaming kernel of a step.  Candidates: the three front-end kernels (once per lane and
     step) and the two image-scale kernels of the feature re-detection (once per RETRACKING lane: weighted by the observed
@@ -377,7 +561,10 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     synchronises inside it) - for a detection kernel the first chunk of every step, whose algorithmic bytes are those of the
     detections it really held (`units_per_launch`, from the per-step result records).  In the pipelined engine other kernels
     share the GPU during those launches, so every candidate is also re-launched alone after the timed region
-    (roam_engine_time_kernel, HIP events on its stream) = `isolated_*`."""
+    (roam_engine_time_kernel, HIP events on its stream) = `isolated_*`.
+    `traffic` = memory-side bytes per launch from the committed PMC passes of that kernel, gfx950-corrected as the microarchitecture
+    guide prescribes (FETCH_SIZE tallies 128-byte requests at 64 bytes: x 2; cross-checked with TCC_MISS x 128 B), scaled to the
+    detections per launch; null when the kernel's source changed after the passes were taken."""
     names = ["ingest_peaks", "warp_quantise", "pyramid"]
     live = {k: v for k, v in live_all.items() if k != "doh_units_per_launch"}
     iso = {k: eng.time_kernel(k, args.kernel_reps) for k in names}
@@ -402,40 +589,28 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     else:
         ms = live.get(dom, iso[dom][0]) if not dom.startswith("doh") else iso[dom][0]
     achieved = algo_bytes / (ms * 1e-3) / 1e9
-    # HBM traffic and VALU instruction counts of that kernel from the PMC passes taken AT THIS LANE COUNT
-    # (profiles/pmc_run.sh -> profiles/pmc_traffic.py); null when no pass at this lane count is committed
-    traffic, valu_frac, src = None, None, None
     kname = {"warp_quantise": "warp_gather_kernel", "ingest_peaks": "peaks_rows_u8_wave_kernel", "pyramid": "pyr_down_wave_kernel",
              "doh_integral": "rt_integral_kernel", "doh_det_maxima": "rt_det_strip_kernel"}[dom]
-    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            # (the detection kernels process `slots` detections per launch whatever the lane count: a pass with lanes == slots
-            #  measures the very same launches)
-            if (tj.get("lanes") == B or (dom.startswith("doh") and tj.get("lanes") == slots)) and kname in tj["kernels"]:
-                k = tj["kernels"][kname]
-                traffic = k.get("traffic_bytes_per_launch")
-                if k.get("valu_wave_insts_per_launch"):
-                    # issue-bound view: VALU wave-instructions x 4 cycles each over 1024 SIMDs, relative to the launch time alone
-                    valu_frac = k["valu_wave_insts_per_launch"] * 4 / (SIMDS * CLOCK_HZ * iso[dom][0] * 1e-3)
-                src = cand
-                break
-        except Exception:
-            continue
-    if dom.startswith("doh") and traffic:
-        traffic = int(traffic * units / slots)                  # the PMC pass measured launches of `slots` detections
+    rec, src = pmc_record(kname)
+    traffic = valu_frac = lds_frac = mem_frac = None
+    detail = None
+    if rec:
+        scale = units / float(rec["units_per_launch"])
+        traffic = int(rec["hbm_bytes_per_launch_corrected"] * scale)
+        iso_s = iso[dom][0] * 1e-3
+        mem_frac = rec["hbm_bytes_per_launch_corrected"] / iso_s / 1e9 / HBM_ACHIEVABLE_GBS
+        if rec.get("valu_wave_insts_per_launch"):
+            valu_frac = rec["valu_wave_insts_per_launch"] * 4 / (SIMDS * CLOCK_HZ * iso_s)       # 4 issue cycles per wave64 instruction
+        if rec.get("lds_active_cycles_per_launch"):
+            lds_frac = rec["lds_active_cycles_per_launch"] / (256 * CLOCK_HZ * iso_s)
+        detail = rec.get("note")
     iso_frac = iso[dom][1] / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
-    bound = "valu_issue" if (valu_frac is not None and valu_frac > iso_frac) else "hbm"
-    detail = {"doh_det_maxima": "float64 box corners out of a 62x94 block of the integral image staged in LDS per 30x62-pixel tile; dxy boxes only where "
-                                "dxx*dyy can pass the threshold (<1 % of the pixels): VALU issue ~49 % and LDS ~47 % busy, HBM fetch 1.4x the algorithmic bytes "
-                                "(halo re-reads that miss L2) - profiles/r02_pmc_det_kernel.txt",
-              "doh_integral": "one sweep, both float64 prefix sums in NumPy's sequential order, image written once (HBM writes = the algorithmic 32.8 MB): "
-                              "1016 dependent phases per detection, each waiting on the row loads of a wave's polar footprint and on LDS (VALU 35 %, LDS 33 %, "
-                              "texture addresser 35 % busy) - profiles/r02_pmc_det_kernel.txt",
-              "warp_quantise": "VALU / LDS issue (round-1 PMC; two rewrites of the per-scan loop measured slower in round 2, DESIGN.md section 6b)"}.get(dom)
-    return {"bound": bound, "bound_detail": detail, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    return {"bound": "hbm", "bound_detail": detail, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
-            "valu_issue_frac_isolated": None if valu_frac is None else round(valu_frac, 4),
+            "traffic_over_algorithmic": None if not traffic else round(traffic / algo_bytes, 3),
+            "isolated_busy_fractions": {"hbm_of_6.3TBs_corrected_traffic": None if mem_frac is None else round(mem_frac, 3),
+                                        "valu_issue": None if valu_frac is None else round(valu_frac, 3),
+                                        "lds_array": None if lds_frac is None else round(lds_frac, 3)},
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
             "units_per_launch": round(units, 1),
             "isolated_achieved": round(iso_frac * HBM_PEAK_GBS, 2), "isolated_frac": round(iso_frac, 5),
@@ -478,9 +653,62 @@ def cpu_baseline(args, seqs, cyc):
     return cpu
 
 
+def run_stream(args):
+    """BASELINE configs 3 / 4 as the reference runs them: ONE sequence (full_seq_1-like motion, unbounded reflector world with
+    movers, scintillation and, with motion distortion on, intra-scan distortion) through a 1-lane engine - frames from a pinned
+    ring on the copy stream, poses through the result ring.  (i) pipelined: steps enqueued as fast as the rings allow = engine-only
+    scan pairs/s of one sequence; (ii) latency: every pose awaited before the next frame is stepped."""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.RawROAMSystem import stream_records
+    n = args.stream_frames
+    md = not args.no_md
+    gold = os.path.join(ROOT, "tests", "golden", "full_seq_1_gt_deltas.npz")
+    deltas = np.load(gold)["deltas"][:n - 1]
+    poses = synth.poses_from_deltas(deltas)
+    jobs = synth.stream_jobs(synth.StreamWorld(11, mover_fraction=0.15), poses, distortion=md, scintillation=0.4)
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(max(1, min(48, (os.cpu_count() or 2) // 2))) as pool:
+        recs = pool.map(synth._render_job, jobs, chunksize=4)
+    ctx = _ffi.Context(0)
+    info = ctx.device_info()
+    flags = {"rejectOutliers": True, "correctMotionDistortion": md}
+    stream_records(iter(recs[:12]), 12, poses[0], flags, ctx)                   # warm-up (allocations, first launches)
+    t0 = time.perf_counter()
+    est, log = stream_records(iter(recs), n, poses[0], flags, ctx)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    est2, log2, lat = stream_records(iter(recs), n, poses[0], flags, ctx, synchronous=True)
+    dt2 = time.perf_counter() - t1
+    assert est.tobytes() == est2.tobytes()
+    ctx.close()
+    lat = np.array(lat) * 1e3
+    rt = np.array([e["retrack"] for e in log], bool)
+    err = np.hypot(*(est[:, :2] - poses[1:, :2]).T)
+    out = {"metric": "radar scan-pairs/sec (400x3768 polar), ONE sequence", "value": round((n - 1) / dt, 2), "unit": "scan-pairs/s",
+           "n_gpus": 1, "steps": n - 1, "warmup": 11, "ms_per_step": round(dt / (n - 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8/f32/f64",
+           "data": f"synthetic Oxford-format records along the first {n - 1} ground-truth motions of full_seq_1 (unbounded reflector world, 15 % movers, scintillation 0.4"
+                   + (", intra-scan distortion)" if md else ")"),
+           "config": {"workload": "single-sequence streaming (BASELINE config " + ("4: motionDistortion ON" if md else "3: motionDistortion OFF")
+                                  + " + outlier rejection): 1 lane, frames uploaded from a pinned ring on the copy stream (host staging copy + PCIe included), every pose read back",
+                      "device": info["name"], "arch": info["arch"], "frames": n,
+                      "pipelined_pairs_per_s": round((n - 1) / dt, 2),
+                      "synchronous_pairs_per_s": round((n - 1) / dt2, 2),
+                      "latency_ms_per_pair": {"median": round(float(np.median(lat)), 3), "p95": round(float(np.percentile(lat, 95)), 3), "max": round(float(lat.max()), 3),
+                                              "median_steady_pair": round(float(np.median(lat[~rt])), 3) if (~rt).any() else None,
+                                              "median_retrack_pair": round(float(np.median(lat[rt])), 3) if rt.any() else None},
+                      "retrack_fraction": round(float(rt.mean()), 4), "keyframes": int(sum(e["new_keyframe"] for e in log)),
+                      "position_rmse_m": round(float(np.sqrt(np.mean(err ** 2))), 3), "distance_m": round(float(np.hypot(*np.diff(poses[:, :2], axis=0).T).sum()), 1)},
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    if args.stream:
+        run_stream(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, argv))
     run_rank(args)

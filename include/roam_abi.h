@@ -286,6 +286,9 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
  * Rendezvous is the caller's business: rank 0 obtains the id, ships the 128 bytes to the other ranks by any means
  * (bench.py: a file), then every rank calls roam_comm_init collectively. */
 #define ROAM_COMM_ID_BYTES 128
+/* 1 if librccl.so can be bound in this process (nothing is initialised): lets the ranks agree on a fallback BEFORE any of them
+ * enters the collective roam_comm_init */
+int32_t roam_comm_available(void);
 int32_t roam_comm_unique_id(uint8_t *id_out /* [ROAM_COMM_ID_BYTES] */);
 int32_t roam_comm_init(roam_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
 int32_t roam_comm_destroy(roam_ctx *ctx);

@@ -66,9 +66,12 @@ class RawROAMSystem:
         return computePosesRMSE(self.gtTraj.getPoseAtTimes(self.estTraj.timestamps), self.estTraj.poses)
 
 
-def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows=400, stride=3779, payload_off=11, clip=2025):
+def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows=400, stride=3779, payload_off=11, clip=2025,
+                   synchronous=False):
     """records: iterator of n_frames (rows, stride) u8 Oxford records of ONE sequence.  -> (poses (n_frames-1, 3), per-pair log).
-    Frame 0 seeds the lane (features detected on the device); frame k is uploaded LOOKAHEAD frames before step k needs it."""
+    Frame 0 seeds the lane (features detected on the device); frame k is uploaded LOOKAHEAD frames before step k needs it.
+    synchronous=True awaits every pose before the next frame is stepped (the latency of one pair instead of the pipeline's
+    rate; same poses) and also returns the per-pair seconds from the step call to the pose on the host."""
     flags = dict(paramFlags or {})
     own = ctx is None
     ctx = ctx or _ffi.Context(int(os.environ.get("ROAM_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
@@ -104,18 +107,26 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
             upload_next()
         eng.synchronize()
         eng.init_lane_detect(0, 0, init_pose)
+        lat = []
         for k in range(1, n_frames):
+            if synchronous:
+                import time
+                t0 = time.perf_counter()
             eng.step([k % RING])
             # slot (k + LOOKAHEAD) % RING last held frame k + LOOKAHEAD - RING <= k - 5: its steps are behind the fence
             eng.fence()
             upload_next()
-            if k - 1 - LAG >= 0:
+            if synchronous:
+                collect(k - 1)
+                lat.append(time.perf_counter() - t0)
+            elif k - 1 - LAG >= 0:
                 collect(k - 1 - LAG)
-        for s in range(max(0, n_frames - 1 - LAG), n_frames - 1):
-            collect(s)
+        if not synchronous:
+            for s in range(max(0, n_frames - 1 - LAG), n_frames - 1):
+                collect(s)
     finally:
         ctx.host_free(pinned)
         eng.close()
         if own:
             ctx.close()
-    return poses, log
+    return (poses, log, lat) if synchronous else (poses, log)

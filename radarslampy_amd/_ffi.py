@@ -94,6 +94,7 @@ _SIGS = {
     "roam_fmt_rotation": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "roam_prune_blobs": (C.c_int32, [_vp, C.c_int32, C.c_double, _vp]),
     "roam_argsort_np122": (C.c_int32, [_vp, C.c_int32, _vp]),
+    "roam_comm_available": (C.c_int32, []),
     "roam_comm_unique_id": (C.c_int32, [_vp]),
     "roam_comm_init": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
     "roam_comm_destroy": (C.c_int32, [_vp]),

@@ -69,6 +69,10 @@ static_assert(sizeof(ncclUniqueId) == ROAM_COMM_ID_BYTES, "ncclUniqueId size");
 
 extern "C" {
 
+// 1 when librccl.so loads and exports what roam_comm_* needs (no communicator, no GPU touched): ranks vote on this BEFORE anyone
+// enters the collective ncclCommInitRank, which has no timeout
+int32_t roam_comm_available(void) { return rccl_api()->handle ? 1 : 0; }
+
 int32_t roam_comm_unique_id(uint8_t *id_out)
 {
     if (!id_out) return ROAM_E_ARG;

@@ -52,12 +52,50 @@ class FileRendezvous:
     def get(self, key: str, rank: int) -> bytes:
         p = os.path.join(self.path, f"{key}.{rank}")
         t0 = time.monotonic()
+        n = 0
         while not os.path.exists(p):
+            n += 1
+            if n % 50 == 0:                                  # a rank that died says so: nobody waits out the timeout for it
+                dead = self.failed_ranks()
+                if dead:
+                    raise RuntimeError(f"rendezvous: rank(s) {dead} failed while rank {self.rank} waited for {key}.{rank}")
             if time.monotonic() - t0 > self.timeout:
                 raise TimeoutError(f"rendezvous: {p} did not appear within {self.timeout} s")
             time.sleep(0.002)
         with open(p, "rb") as f:
             return f.read()
+
+    def mark_failed(self, why: str = ""):
+        """called by a rank (or by the launcher on its behalf) that cannot go on"""
+        try:
+            self.put("failed", why.encode()[:2000])
+        except OSError:
+            pass
+
+    def failed_ranks(self):
+        try:
+            return sorted(int(f.split(".")[1]) for f in os.listdir(self.path) if f.startswith("failed.") and f.split(".")[1].isdigit())
+        except OSError:
+            return []
+
+    def watchdog(self, period: float = 0.25):
+        """daemon thread: leave the process (exit code 3) as soon as ANOTHER rank reports failure - a rank blocked inside an
+        RCCL collective cannot be interrupted any other way, and must not keep its GPU"""
+        import threading
+
+        def run():
+            while True:
+                time.sleep(period)
+                dead = [r for r in self.failed_ranks() if r != self.rank]
+                if dead:
+                    import sys
+                    sys.stderr.write(f"[rank {self.rank}] rank(s) {dead} failed - exiting\n")
+                    sys.stderr.flush()
+                    os._exit(3)
+
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        return t
 
     def gather(self, tag: str, data: bytes):
         """every rank contributes `data`; returns the list of all contributions (also a barrier)"""
@@ -108,9 +146,12 @@ class FileComm:
             self.rdv.put(key, blob)
         d = json.loads(self.rdv.get(key, root))
         self.barrier()
-        return dict(pose=np.array(d["pose"], np.float64), velocity=np.array(d["velocity"], np.float64),
-                    prunedUndistortedLocals=np.array(d["prunedUndistortedLocals"], np.float64).reshape(-1, 2),
-                    peaks=np.array(d["peaks"], np.int32).reshape(-1, 2), scan=int(d["scan"]), lane=int(d["lane"]))
+        kf = dict(pose=np.array(d["pose"], np.float64), velocity=np.array(d["velocity"], np.float64),
+                  prunedUndistortedLocals=np.array(d["prunedUndistortedLocals"], np.float64).reshape(-1, 2),
+                  peaks=np.array(d["peaks"], np.int32).reshape(-1, 2), scan=int(d["scan"]), lane=int(d["lane"]))
+        if hasattr(engine, "remote_map_add"):                # the consumer (Map.addKeyframe on every rank), stand-in side
+            engine.remote_map_add(dict(kf, root=root))
+        return kf
 
     def close(self):
         self.barrier()
@@ -137,6 +178,11 @@ class _stdout_to_stderr:
 class RcclComm:
     """RCCL communicator of one context (roam_comm_*): ncclUniqueId of rank 0 travels through the rendezvous directory."""
     backend = "rccl"
+
+    @staticmethod
+    def available(ctx) -> bool:
+        """can librccl.so be bound in this process?  (no communicator is created: safe to call before the ranks have agreed)"""
+        return bool(ctx.lib.roam_comm_available())
 
     def __init__(self, ctx, rdv: FileRendezvous):
         import ctypes as C

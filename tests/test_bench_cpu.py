@@ -26,6 +26,8 @@ def _check(d, world, launcher):
     if world > 1:
         assert d["config"]["collective_backend"] == "file" and d["config"]["comm_rank_world_seen"] == [0, world]
         assert d["config"]["keyframe_broadcast_ms"] is not None
+        # the consumer of the broadcast: every rank's global map holds the warm-up keyframe + one from every rank
+        assert d["config"]["global_map_keyframes_and_senders"] == [world + 1, list(range(world))]
 
 
 def test_bench_single_process_dry():
@@ -47,3 +49,29 @@ def test_bench_under_torch_distributed_run_world2():
                         "--master-port", "29631", BENCH, "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     _check(_line(r.stdout), 2, "torch.distributed.run env")
+
+
+def test_launcher_ends_quickly_and_nonzero_when_a_rank_dies():
+    """rank 1 raises in its second step while rank 0 is on its way into a barrier: the launcher notices the exit code, tells the
+    survivor through the rendezvous directory, and returns non-zero within seconds - nobody waits out a 300 s rendezvous timeout
+    (on a GPU box: nobody stays blocked in an RCCL collective holding its GPU)"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["ROAM_DRY_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=60, env=env)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0 and dt < 10.0, (r.returncode, dt)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no result line from a broken run
+    assert "rank(s) [1] exited" in r.stderr and "injected failure" in r.stderr, r.stderr[-1500:]
+
+
+def test_launcher_refuses_more_ranks_than_gpus(monkeypatch):
+    """the GPU count comes from the KFD topology in sysfs - the launcher itself never initialises HIP"""
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.visible_gpu_count()
+    assert n is None or n >= 0
+    src = open(BENCH).read()
+    launcher = src[src.index("def visible_gpu_count"):src.index("# ------------------------------------------------------------------------------------------------ engines")]
+    assert "_ffi" not in launcher and "Context(" not in launcher and "load_library" not in launcher
