@@ -41,10 +41,13 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=None, help="independent sequences resident per GPU (default 4096; 1024 with --h2d)")
     ap.add_argument("--frames", type=int, default=7, help="frames per synthetic sequence (played ping-pong)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic sequences generated per rank")
+    ap.add_argument("--endless", action="store_true", help="round-2 workload: every lane plays ONE endless ping-pong sequence (no new sequences): the retrack rate then decays with the number of steps played")
+    ap.add_argument("--preroll", type=int, default=16, help="untimed steps before the warm-up (not counted in it): every lane goes through a few retrack cycles of its own, so that the retrack rate of the timed steps is the stationary one")
     ap.add_argument("--render-procs", type=int, default=0, help="processes rendering the synthetic sequences (0 = min(distinct, cores / 2))")
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N launcher: wall-clock limit for the whole run, seconds")
     ap.add_argument("--stream", action="store_true", help="single-sequence mode: one lane, pinned ring, result ring (configs 3 / 4)")
     ap.add_argument("--stream-frames", type=int, default=240, help="frames of the --stream sequence")
+    ap.add_argument("--stream-start", type=int, default=280, help="first ground-truth motion of full_seq_1 used by --stream (the vehicle stands still for the first ~230 frames)")
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle, 1 core (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the N-core CPU leg (-1 = half the logical cores, 0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
@@ -229,12 +232,6 @@ def render_sequences(seeds, frames, md, work, procs):
         return pool.map(_render_sequence, jobs)
 
 
-# a lane keeps this fraction of its first detection: lanes enter the timed loop at different points of their retrack cycle
-# (they would otherwise all run out of features in the same steps: every lane detects ~200 features at set-up and loses
-# the same ~26 % per pair)
-AGE_FRACTIONS = (1.0, 0.86, 0.74, 0.64, 0.55, 0.47, 0.40, 0.34)
-
-
 def run_rank(args):
     from radarslampy_amd import distributed as D
     rank, local_rank, world = D.rank_env()
@@ -260,7 +257,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         eng = DryEngine(B, rank)
         engs, ctxs, info = [eng], [], dict(name="dry", arch="none")
         comm = D.FileComm(rdv) if rdv else None
-        step_all = lambda i: eng.step(np.zeros(B, np.int32))       # noqa: E731
+        step_all = lambda i, sequences_end=True: eng.step(np.zeros(B, np.int32)) or 0       # noqa: E731
         seqs = None
     else:
         # workload: reflector world with 120 movers and scan-to-scan scintillation: ~26 % of the tracked correspondences are
@@ -299,14 +296,6 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         period = 2 * T - 2
         cyc_full = list(range(T)) + list(range(T - 2, 0, -1))          # ping-pong 0,1,..,T-1,T-2,..,1
 
-        def age_lanes(en, nb):
-            """thin the first detections (AGE_FRACTIONS): lane b keeps a leading share of its features, in detection order"""
-            for b in range(nb):
-                f = AGE_FRACTIONS[(b // Dn_ + b) % len(AGE_FRACTIONS)]
-                if f < 1.0:
-                    feat = en.lane_features(b)
-                    en.set_features(b, feat[:max(61, int(len(feat) * f))])
-
         for e in range(E):
             en = Engine(BE, BE * T, ctx=ctxs[e], motion_distortion=not args.no_md, retrack_on_device=not args.no_retrack,
                         retrack_slots=args.retrack_slots)
@@ -327,14 +316,26 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             else:
                 # first features detected on the device (DoH + ANMS), all lanes in one pass
                 en.init_lanes_detect(0, [b * T + t0s[b] for b in range(BE)], np.array([seqs[b % Dn][1][t0s[b]] for b in range(BE)]))
-                age_lanes(en, BE)
             engs.append(en)
         eng = engs[0]
         cyc_arr = np.array(cyc_full)
 
-        def step_all(i):
+        # A lane is a STREAM OF FINITE SEQUENCES: its T frames forward and backward (2T - 2 scans, one fewer pairs - the reference's
+        # own data/tiny is 11 scans), then the next sequence begins on frame 0 with a first-frame detection and no pair
+        # (ROAM_STEP_NEW_SEQUENCE).  Lanes are spread over the phases of that cycle, so in every step the same share of them is 0, 1,
+        # .. 2T - 3 pairs into its sequence: feature ages, rejection rate and retrack rate are stationary, whatever steps are timed.
+        # (A single endless ping-pong is not: the features that survive a few passes are the stable ones, and the retrack rate
+        # decays for hundreds of steps.)
+        new_seq = 0 if (args.no_retrack or args.endless) else _ffi.STEP_NEW_SEQUENCE
+
+        def step_all(i, sequences_end=True):
+            n_new = 0
             for en in engs:
-                en.step((np.arange(BE) * T + cyc_arr[(en.phase + i + 1) % period]).astype(np.int32))
+                ph = (en.phase + i + 1) % period
+                starts = (ph == 0) & (new_seq != 0) & sequences_end
+                en.step(((np.arange(BE) * T + cyc_arr[ph]) | np.where(starts, new_seq, 0)).astype(np.int32))
+                n_new += int(np.count_nonzero(starts))
+            return n_new
 
         if args.h2d:
             # PCIe-inclusive mode (f2): one engine, pool = two halves of B slots; lanes of one sequence are contiguous so
@@ -365,14 +366,14 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
                     eng.init_lane(b, b, seqs[lane_seq[b]][2], seqs[lane_seq[b]][1][0])
             else:
                 eng.init_lanes_detect(0, np.arange(B), np.array([seqs[lane_seq[b]][1][0] for b in range(B)]))
-                age_lanes(eng, B)
             upload(0, 1)
 
-            def step_all(i):                                   # noqa: F811
+            def step_all(i, sequences_end=True):               # noqa: F811
                 half = (i + 1) % 2                             # scans of step i live in half (i+1)%2 (step 0 -> half 1)
                 eng.fence()
                 eng.step(np.arange(B, dtype=np.int32) + half * B)
                 upload(i + 1, i % 2)
+                return 0
 
     def barrier():
         for en in engs:
@@ -401,18 +402,20 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         retracks_per_step.append(tot)
 
     s = 0
-    for _ in range(args.warmup):
+    pre = 0 if (args.dry_engine or args.no_retrack) else max(0, args.preroll)
+    for _ in range(pre + args.warmup):
         step_all(s); s += 1
     barrier()
     t0 = time.perf_counter()
+    first_frames = 0                                           # lanes x steps that opened a new sequence (a scan, but no pair)
     for k in range(args.steps):
-        step_all(s); s += 1
+        first_frames += step_all(s); s += 1
         if k >= 2:
             consume(s - 3)
     barrier()
     dt = time.perf_counter() - t0
     for k in range(max(0, args.steps - 2), args.steps):
-        consume(args.warmup + k)
+        consume(pre + args.warmup + k)
     res = eng.results()
     # in-step kernel durations of the K timed steps (HIP event pairs recorded by the engine on the kernels' own streams), taken NOW:
     # the steady / forced segments below enqueue more steps
@@ -422,7 +425,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         live = {k: eng.kernel_avg(k, args.steps)[0] for k in knames}
         if not args.no_retrack:
             slots_ = min(B // len(engs), args.retrack_slots or 512)
-            per = [min(slots_, stat.get("per_step", {}).get(args.warmup + k, 0)) for k in range(args.steps)]
+            per = [min(slots_, stat.get("per_step", {}).get(pre + args.warmup + k, 0)) for k in range(args.steps)]
             live["doh_units_per_launch"] = float(np.mean(per)) if per else 0.0      # detections in the first chunk of a step, on average
     if comm is not None:
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
@@ -459,7 +462,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         barrier()
         t1 = time.perf_counter()
         for _ in range(k2):
-            step_all(s); s += 1
+            step_all(s, False); s += 1
         for en in engs:
             en.synchronize()
         extra["steady_pairs_per_s"] = round(B * k2 / (time.perf_counter() - t1), 1)
@@ -467,7 +470,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         extra["steady_mean_tracked"] = round(float(np.mean([en.results_array()["n_tracked"].mean() for en in engs])), 1)
         for en in engs:
             en.set_retrack(2)                                   # every lane re-detects: the cost of a retrack pair
-        step_all(s); s += 1
+        step_all(s, False); s += 1
         for en in engs:
             en.synchronize()
         st_forced = eng.stage_times()
@@ -481,7 +484,9 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
 
     out = None
     if rank == 0:
-        pairs = B * args.steps * world
+        # scan PAIRS: a lane's step that opens a new sequence consumes a scan (ingest, warp, pyramid, peaks, first-frame detection)
+        # but yields no pair - it is not counted (the same share on every rank: phases are assigned alike)
+        pairs = (B * args.steps - first_frames) * world
         value = pairs / dt
         rps = retracks_per_step[-args.steps:] if retracks_per_step else []
         out = {
@@ -490,12 +495,13 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
             "data": f"synthetic Oxford-format 400x3779 u8 records; {Dn_} distinct seeded sequences x {T} frames per rank (460 static reflectors + "
                     + ("24 movers" if args.no_retrack else "120 movers, scan-to-scan scintillation 0.6") + f"), replicated into {B} lane-private HBM copies, ping-pong replay with staggered phases"
-                    + ("" if args.no_retrack else "; lanes start from device-side detections thinned to 34-100 % so that their retrack cycles are out of step"),
+                    + ("" if (args.no_retrack or args.endless) else f"; every lane is a stream of finite sequences ({2 * T - 2} scans = {2 * T - 3} pairs each, first frame detected on the device), lanes spread evenly over the phases"),
             "config": {"workload": "scan pair, full hot path (ingest+peaks, warp, pyramid, KLT, max-clique outlier rejection, Kabsch, "
                                    + ("motion-distortion LM" if not args.no_md else "dead reckoning")
                                    + (", keyframe bookkeeping; features host-seeded, no re-detection)" if args.no_retrack else
                                       ", keyframe bookkeeping, DoH + ANMS re-detection on the device whenever a lane runs out of features; every lane's pose read back every step)"),
-                       "lanes_per_gpu": B, "engines_per_gpu": len(engs), "h2d_streaming": bool(args.h2d), "frames": T, "distinct_sequences": Dn_,
+                       "lanes_per_gpu": B, "engines_per_gpu": len(engs), "preroll_steps": pre,
+                       "scans_per_step": B, "first_frame_scans_in_timed_steps": first_frames, "pairs_counted": (B * args.steps - first_frames), "h2d_streaming": bool(args.h2d), "frames": T, "distinct_sequences": Dn_,
                        "device": info["name"], "arch": info["arch"], "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("bench.py --gpus" if world > 1 else "single process"),
                        "collective_backend": None if comm is None else comm.backend,
                        "comm_rank_world_seen": comm_seen, "global_map_keyframes_and_senders": map_seen,
@@ -663,7 +669,7 @@ def run_stream(args):
     n = args.stream_frames
     md = not args.no_md
     gold = os.path.join(ROOT, "tests", "golden", "full_seq_1_gt_deltas.npz")
-    deltas = np.load(gold)["deltas"][:n - 1]
+    deltas = np.load(gold)["deltas"][args.stream_start:args.stream_start + n - 1]
     poses = synth.poses_from_deltas(deltas)
     jobs = synth.stream_jobs(synth.StreamWorld(11, mover_fraction=0.15), poses, distortion=md, scintillation=0.4)
     import multiprocessing as mp
@@ -687,7 +693,7 @@ def run_stream(args):
     out = {"metric": "radar scan-pairs/sec (400x3768 polar), ONE sequence", "value": round((n - 1) / dt, 2), "unit": "scan-pairs/s",
            "n_gpus": 1, "steps": n - 1, "warmup": 11, "ms_per_step": round(dt / (n - 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8/f32/f64",
-           "data": f"synthetic Oxford-format records along the first {n - 1} ground-truth motions of full_seq_1 (unbounded reflector world, 15 % movers, scintillation 0.4"
+           "data": f"synthetic Oxford-format records along ground-truth motions {args.stream_start}..{args.stream_start + n - 2} of full_seq_1 (unbounded reflector world, 15 % movers, scintillation 0.4"
                    + (", intra-scan distortion)" if md else ")"),
            "config": {"workload": "single-sequence streaming (BASELINE config " + ("4: motionDistortion ON" if md else "3: motionDistortion OFF")
                                   + " + outlier rejection): 1 lane, frames uploaded from a pinned ring on the copy stream (host staging copy + PCIe included), every pose read back",

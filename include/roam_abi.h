@@ -222,6 +222,11 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
  * synchronised execution; roam_engine_results and the other blocking accessors return the state
  * after the LAST enqueued step.  The host may run at most three steps ahead of the device. */
 int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx);
+/* scan_idx[i] | ROAM_STEP_NEW_SEQUENCE: lane i starts a NEW sequence on this scan - its features are dropped before the pair,
+ * nothing is tracked, the pose stays, and the first-frame detection (appendNewFeatures(prevImgCart, empty),
+ * RawROAMSystem.py:150) runs on this scan inside the step (needs cfg.retrack_on_device).  A stream of finite sequences
+ * per lane without any host synchronisation between them. */
+#define ROAM_STEP_NEW_SEQUENCE 0x40000000
 /* blocking: fetch the per-lane results of the last step */
 int32_t roam_engine_results(roam_ctx *ctx, roam_lane_result *out, int32_t n);
 /* per-step results without draining the pipeline: every step's records are copied to pinned host memory right behind the step

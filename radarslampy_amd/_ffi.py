@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("ROAM_LIB") or os.path.join(_HERE, "csrc", "libroam_hi
 
 ROAM_OK, ROAM_E_ARG, ROAM_E_HIP, ROAM_E_CAPACITY, ROAM_E_NODEVICE, ROAM_E_STATE = 0, -1, -2, -3, -4, -5
 MAX_FEATURES = 1024
+STEP_NEW_SEQUENCE = 0x40000000      # roam_abi.h ROAM_STEP_NEW_SEQUENCE: OR into a lane's scan index
 
 
 class RoamError(RuntimeError):

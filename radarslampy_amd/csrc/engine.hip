@@ -48,7 +48,7 @@ struct Engine {
     int32_t *row_count = nullptr;
     int32_t *peaks_out[3] = {nullptr, nullptr, nullptr}, *peaks_n[3] = {nullptr, nullptr, nullptr};   // ring of 3 (stage A runs 2 steps ahead of g4)
     int32_t *scan_idx[3] = {nullptr, nullptr, nullptr};
-    int32_t *scan_host = nullptr;       // pinned staging of the scan indices (3 x B)
+    int32_t *scan_host = nullptr;       // pinned staging of the scan indices + new-sequence flags (3 x 2B)
     int pk = 0;                         // ring slot of the latest step (valid peak / scan-index buffers)
     int64_t nstep = 0;
     float *feat = nullptr;              // B x KS x 2
@@ -149,6 +149,12 @@ __device__ __forceinline__ int blk_excl_scan(int v, int *sh, int *total)
     __syncthreads();
     *total = tot;
     return base + inc - v;
+}
+
+__global__ void new_sequence_kernel(int32_t *__restrict__ feat_n, const int32_t *__restrict__ flag, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && flag[b]) feat_n[b] = 0;
 }
 
 // G1: status &= err < ERR_THRESHOLD (getTransformKLT.py:365), ordered compaction of the good pairs
@@ -497,9 +503,9 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     for (int i = 0; i < 3; i++) {
         ok = ok && dalloc(ctx, e, &e->peaks_out[i], (size_t)B * cfg->peaks_cap * 2);
         ok = ok && dalloc(ctx, e, &e->peaks_n[i], (size_t)B);
-        ok = ok && dalloc(ctx, e, &e->scan_idx[i], (size_t)B);
+        ok = ok && dalloc(ctx, e, &e->scan_idx[i], 2 * (size_t)B);     // [0, B): pool scan of each lane; [B, 2B): 1 = the lane starts a new sequence
     }
-    if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->scan_host), sizeof(int32_t) * 3 * (size_t)B, hipHostMallocDefault) != hipSuccess) {
+    if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->scan_host), sizeof(int32_t) * 6 * (size_t)B, hipHostMallocDefault) != hipSuccess) {
         ROAM_SET_ERR(ctx, "engine: hipHostMalloc failed"); ok = false;
     }
     ok = ok && dalloc(ctx, e, &e->feat, (size_t)B * KS * 2);
@@ -961,8 +967,11 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     ENGINE();
     ARG_CHECK(ctx, scan_idx);
     const int B = e->B;
-    for (int b = 0; b < B; b++) ARG_CHECK(ctx, scan_idx[b] >= 0 && scan_idx[b] < e->cfg.pool_scans);
-    for (int b = 0; b < B; b++) e->last_scan[b] = scan_idx[b];
+    for (int b = 0; b < B; b++) ARG_CHECK(ctx, scan_idx[b] >= 0 && (scan_idx[b] & ~ROAM_STEP_NEW_SEQUENCE) < e->cfg.pool_scans);
+    for (int b = 0; b < B; b++) e->last_scan[b] = scan_idx[b] & ~ROAM_STEP_NEW_SEQUENCE;
+    bool any_new = false;
+    for (int b = 0; b < B; b++) any_new = any_new || (scan_idx[b] & ROAM_STEP_NEW_SEQUENCE);
+    if (any_new && !(e->rt_on && e->rt_mode)) { ROAM_SET_ERR(ctx, "ROAM_STEP_NEW_SEQUENCE needs device-side detection (retrack_on_device, mode >= 1)"); return ROAM_E_STATE; }
     hipStream_t st = ctx->stream;
     const roam_engine_cfg &c = e->cfg;
     const int nw = KS / 64;
@@ -989,10 +998,10 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     // (lane initialisation, retracks and synchronous uploads finish on the host before a step is enqueued)
     if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(sA, ctx->ev_up, 0)); e->uploads_pending = false; }
     if (e->pool_dirty) { HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_pool, 0)); e->pool_dirty = false; }   // device-to-device record copies
-    int32_t *hs = e->scan_host + (size_t)pb * B;
+    int32_t *hs = e->scan_host + (size_t)pb * 2 * B;
     if (e->nstep >= 3) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[w4]));   // the staging slot's last copy has long been consumed
-    for (int b = 0; b < B; b++) hs[b] = scan_idx[b];
-    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, sA));
+    for (int b = 0; b < B; b++) { hs[b] = scan_idx[b] & ~ROAM_STEP_NEW_SEQUENCE; hs[B + b] = (scan_idx[b] & ROAM_STEP_NEW_SEQUENCE) ? 1 : 0; }
+    HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * 2 * (size_t)B, hipMemcpyHostToDevice, sA));
     hipEvent_t *tr = e->tr_ev[e->nstep & 63];
     // the peak kernel gets its own stream: it only needs the scan indices (event ev_idx) and is joined before g4
     hipStream_t sP = ctx->stream5;
@@ -1017,6 +1026,12 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipEventRecord(e->ev_join, sB));                         // end of stage B
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
+    if (any_new) {
+        // lanes that start a NEW sequence on this scan drop their features: nothing is tracked, the pose stays, and the retrack
+        // branch detects the sequence's first features on this scan (appendNewFeatures(prevImgCart, empty), RawROAMSystem.py:150)
+        hipLaunchKernelGGL(new_sequence_kernel, dim3((B + 255) / 256), dim3(256), 0, st, e->feat_n, e->scan_idx[pb] + B, B);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, launch_klt(st, prev, next, e->pd, e->feat, e->feat_n, KM, KS, B, e->klt_next, e->klt_status, e->klt_err));
     HIP_TRY(ctx, hipEventRecord(e->ev_klt[k4], st));
     hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,

@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 // A is bound by load latency, B by the latency of 64 x RI_WAVES dependent float64 additions, and they hide each other.
 // Both cumulative sums keep NumPy's sequential order; the float64 image is written ONCE (32.8 MB per detection instead of the
 // 98.6 MB moved by the two-pass kernels above, which stay for small chunks - see rt_one_sweep - and for image sizes above 2048).
+#ifndef RI_ROWS
 #define RI_ROWS 16
+#endif
 #define RI_WAVES 4
 #define RI_GROUPS (2048 / (64 * RI_WAVES))
 #define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8)

@@ -371,3 +371,38 @@ def test_lanes_that_grow_past_320_features_are_tracked_in_full():
         _same_pose(got, want, b)
     eng.close()
     ctx.close()
+
+
+def test_new_sequence_flag_restarts_a_lane_inside_the_step():
+    """scan_idx | ROAM_STEP_NEW_SEQUENCE: the lane drops its features before the pair - nothing is tracked, the pose stays, the
+    first-frame detection runs on this scan (retrack path) - while its neighbour goes on; the following pairs equal the
+    oracle's loop body started from that state"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(31, 5, n_movers=6, distortion=True)
+    ctx = _ffi.Context(0)
+    eng = Engine(2, 5, ctx=ctx, retrack_on_device=True)
+    for t in range(5):
+        eng.upload_scan(t, recs[t])
+    pipes = []
+    for b in range(2):
+        eng.init_lane(b, 0, feat, poses[0])
+        pipes.append(oracle.OdometryPipeline(recs[0], feat, poses[0], detect=_detect))
+    for t in (1, 2, 3, 4):
+        restart = t == 2
+        eng.step([t | (_ffi.STEP_NEW_SEQUENCE if restart else 0), t])
+        res = eng.results()
+        if restart:
+            pipes[0].blobCoord = np.empty((0, 2), np.float32)            # the new sequence starts with no features
+        for b in range(2):
+            want = pipes[b].step(recs[t])
+            got = res[b]
+            assert got["n_tracked"] == want["n_tracked"] and got["n_inliers"] == want["n_inliers"], (t, b)
+            assert got["retrack"] == bool(want["retrack"]), (t, b)
+            assert np.array_equal(eng.lane_features(b), pipes[b].blobCoord), (t, b)
+            _same_pose(got, want, (t, b))
+        if restart:
+            assert res[0]["n_tracked"] == 0 and res[0]["retracked_on_device"] and 180 <= res[0]["n_after_retrack"] <= 220
+            assert not res[1]["retracked_on_device"]
+    eng.close()
+    ctx.close()
