@@ -126,6 +126,21 @@ def convertPolarImageToCartesian(imgPolar: np.ndarray, want_u8: bool = False):
     return (cart, u8) if want_u8 else cart
 
 
+def convertPolarImageToCartesianTies(imgPolar: np.ndarray, tie_eps: float, want_u8: bool = False, every: int = 1):
+    """sensitivity probe: the same warp with every `every`-th radial sampling coordinate within tie_eps (in 1/32-px units) of a rounding tie
+    rounded the OTHER way - what an ulp of difference in the radius (IPP's magnitude in the reference's cv2 build, DESIGN.md
+    section 4) can do.  -> (cart[, u8], number of such pixels)"""
+    img = np.ascontiguousarray(imgPolar, dtype=np.float32)
+    rows, cols = img.shape
+    W = 2 * (cols // 2)
+    cart = np.empty((W, W), np.float32)
+    u8 = np.empty((W, W), np.uint8) if want_u8 else None
+    lib().oracle_polar_to_cart_ties.restype = C.c_int64
+    n = lib().oracle_polar_to_cart_ties(_p(img, C.c_float), rows, cols, C.c_int64(cols), _p(cart, C.c_float),
+                                        _p(u8, C.c_uint8) if want_u8 else None, C.c_float(tie_eps), int(every))
+    return (cart, u8, int(n)) if want_u8 else (cart, int(n))
+
+
 def quantize_u8(img: np.ndarray) -> np.ndarray:
     """(img*255).astype(np.uint8), getTransformKLT.py:356-357."""
     img = np.ascontiguousarray(img, np.float32)
@@ -600,8 +615,9 @@ class OdometryPipeline:
     (`detect(cart_f32) -> (k,2) [x,y]`) because blob_doh is a separate, unpinned stage."""
 
     def __init__(self, first_record_u8, init_features_xy, init_pose, reject_outliers=True,
-                 motion_distortion=True, detect=None, payload_off=11, clip=MAX_RANGE_CLIP_PX):
+                 motion_distortion=True, detect=None, payload_off=11, clip=MAX_RANGE_CLIP_PX, warp=None):
         self.off, self.clip = payload_off, clip
+        self.warp = warp or (lambda polar: convertPolarImageToCartesian(polar, want_u8=True))     # polar f32 -> (cart f32, cart u8)
         self.reject, self.md, self.detect = reject_outliers, motion_distortion, detect
         self.MDS = MotionDistortionSolver(np.diag([4, 4]), np.diag([1, 1, (5 * np.pi / 180) ** 2]))
         self.prev_pose = convertPoseToTransform(init_pose)
@@ -615,7 +631,7 @@ class OdometryPipeline:
 
     def _cart_u8(self, rec):
         polar = rec[:, self.off:self.off + self.clip].astype(np.float32) / 255.
-        return convertPolarImageToCartesian(polar, want_u8=True)[1]
+        return self.warp(polar)[1]
 
     def step(self, rec_u8):
         cur8 = self._cart_u8(rec_u8)
@@ -659,7 +675,7 @@ class OdometryPipeline:
         newkf = retrack or dth >= ROT_THRESHOLD or dtr >= TRANS_THRESHOLD_SQ
         if newkf:
             if retrack and self.detect is not None:
-                cart_f32 = convertPolarImageToCartesian(rec_u8[:, self.off:self.off + self.clip].astype(np.float32) / 255.)
+                cart_f32 = self.warp(rec_u8[:, self.off:self.off + self.clip].astype(np.float32) / 255.)[0]
                 good_new = append_dedupe(good_new, self.detect(cart_f32))
                 centered_new = (good_new - RADAR_CART_CENTER) * RANGE_RESOLUTION_CART_M
             self.old_kf = Keyframe(pose, centered_new, None, velocity, with_peaks=False)

@@ -84,9 +84,10 @@ static inline float polar_tap(const float *polar, int rows, int cols, int64_t st
 
 /* polar (rows x cols f32) -> cart (2R x 2R f32), R = cols/2.  Optionally also the u8
  * quantisation the KLT wrapper applies.  Either output may be NULL. */
-void oracle_polar_to_cart(const float *polar, int rows, int cols, int64_t stride,
-                          float *cart_f32, uint8_t *cart_u8)
+static int64_t polar_to_cart_impl(const float *polar, int rows, int cols, int64_t stride,
+                                  float *cart_f32, uint8_t *cart_u8, float tie_eps, int tie_every)
 {
+    int64_t n_flipped = 0, n_ties = 0;
     const int R = cols / 2;
     const int W = 2 * R;
     const double Kangle = 6.283185307179586476925286766559 / rows;
@@ -105,6 +106,12 @@ void oracle_polar_to_cart(const float *polar, int rows, int cols, int64_t stride
             float my = (float)phi + 1.f;
             int sx = cv_round_f(mx * 32.f);
             int sy = cv_round_f(my * 32.f);
+            if (tie_eps > 0.f) {
+                /* the radial coordinate within tie_eps of a rounding tie of the 1/32-px grid: take the OTHER neighbour (what a
+                 * magnitude that differs by an ulp - IPP's ippsMagnitude_32f in the reference's cv2 build - can do) */
+                float t = mx * 32.f, fl = floorf(t), fr = t - fl;
+                if (fabsf(fr - 0.5f) < tie_eps && (n_ties++ % tie_every) == 0) { sx = (sx == (int)fl) ? (int)fl + 1 : (int)fl; n_flipped++; }
+            }
             int ix = sx >> 5, iy = sy >> 5;
             int fxq = sx & 31, fyq = sy & 31;
             float wx1 = (float)fxq * (1.f / 32.f), wx0 = 1.f - wx1;
@@ -126,6 +133,21 @@ void oracle_polar_to_cart(const float *polar, int rows, int cols, int64_t stride
             }
         }
     }
+    return n_flipped;
+}
+
+void oracle_polar_to_cart(const float *polar, int rows, int cols, int64_t stride,
+                          float *cart_f32, uint8_t *cart_u8)
+{
+    polar_to_cart_impl(polar, rows, cols, stride, cart_f32, cart_u8, 0.f, 1);
+}
+
+/* sensitivity probe (tests/test_oracle_reference_dump.py): the same warp with every tie_every-th radial sampling coordinate that
+ * lies within tie_eps of a rounding tie rounded the other way; returns the number of pixels treated so */
+int64_t oracle_polar_to_cart_ties(const float *polar, int rows, int cols, int64_t stride,
+                                  float *cart_f32, uint8_t *cart_u8, float tie_eps, int tie_every)
+{
+    return polar_to_cart_impl(polar, rows, cols, stride, cart_f32, cart_u8, tie_eps, tie_every < 1 ? 1 : tie_every);
 }
 
 /* (img*255).astype(uint8) on an arbitrary f32 image in [0,1] */
