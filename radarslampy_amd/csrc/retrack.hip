@@ -782,13 +782,30 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     const double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
     double *kp = a.kp + (int64_t)ls * BP_MAX_PTS * 3;
     int flags = ncand > BP_MAX_PTS ? RT_F_CAND_OVERFLOW : 0;
-    // 1. response order: peak_local_max sorts by -intensity; equal responses keep the C (row, col, layer) order
-    for (int i = lane; i < n; i += 64) {
-        const double vi = cval[i];
-        int rank = 0;
-        for (int j = 0; j < n; j++) { const double vj = cval[j]; rank += (vj > vi || (vj == vi && j < i)) ? 1 : 0; }
-        const uint32_t p = crc[i];
-        L.xy[2 * rank] = (int16_t)(p >> 16); L.xy[2 * rank + 1] = (int16_t)((p >> 2) & 0x3fff); L.lay[rank] = (uint8_t)(p & 3);
+    // 1. response order: peak_local_max sorts by -intensity; equal responses keep the C (row, col, layer) order.  The responses are
+    // staged in LDS (the set tables are free until step 5) and every lane ranks four candidates per pass against broadcast reads
+    // (straight out of global memory the n^2 / 64 dependent loads were a sixth of this kernel)
+    double *sval = reinterpret_cast<double *>(L.tabB);
+    for (int i = lane; i < n; i += 64) sval[i] = cval[i];
+    __syncthreads();
+    for (int i0 = lane; i0 < n; i0 += 256) {
+        double vi[4];
+        int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; u++) vi[u] = i0 + 64 * u < n ? sval[i0 + 64 * u] : 0.0;
+        for (int j = 0; j < n; j++) {
+            const double vj = sval[j];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rank[u] += (vj > vi[u] || (vj == vi[u] && j < i0 + 64 * u)) ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u;
+            if (i < n) {
+                const uint32_t p = crc[i];
+                L.xy[2 * rank[u]] = (int16_t)(p >> 16); L.xy[2 * rank[u] + 1] = (int16_t)((p >> 2) & 0x3fff); L.lay[rank[u]] = (uint8_t)(p & 3);
+            }
+        }
     }
     __syncthreads();
     // 2. cKDTree, level by level: every node of a level is built by its own lane (bounds, libstdc++ nth_element, scipy's
