@@ -754,29 +754,50 @@ __global__ __launch_bounds__(256) void rt_emit_kernel(RtArgs a, int first)
 }
 
 // ------------------------------------------------------------------------------------------------ K5: blob bookkeeping
-#define RT_PL 3328                      // (what the 64 KB of static LDS leave)
-struct RtBlobLds {
-    int16_t xy[2 * BP_MAX_PTS];       // [row, col] in response order
-    int16_t idx[BP_MAX_PTS];          // cKDTree.indices, later the aquicksort permutation
-    uint8_t lay[BP_MAX_PTS];          // layer (1 | 2) in response order; 0 = pruned
-    BpNode nodes[BP_MAX_NODES];
+// Two capacity classes.  The tables of the FULL class (2048 candidates, 4914 pairs in the LDS set tables) take 64 KB: two workgroups - two
+// detections - per CU, while a real or synthetic scan has 250-600 candidates and a few hundred to 1400 pairs.  The SMALL class (1024
+// candidates, 1228 pairs: the set then never grows past 2048 entries) takes 33 KB: four detections per CU.  Every detection goes
+// through the small kernel first; one that does not fit (more candidates, tree nodes or pairs) is left untouched and marked for the
+// full kernel, which runs right after it and returns at once for everything else.
+template <bool SMALL> struct RtBlobCap {
+    static constexpr int NP = SMALL ? 1024 : BP_MAX_PTS;
+    static constexpr int NNODE = SMALL ? 320 : BP_MAX_NODES;
+    static constexpr int CAPA = 2048, CAPB = SMALL ? 4096 : 8192;          // set tables (entries); tabB also holds NP packed points / doubles
+    static constexpr int LDS_PAIRS = SMALL ? 1228 : BP_LDS_PAIRS;          // below this count the set never outgrows the tables
+    static constexpr int NPL = SMALL ? 1280 : 3328;                        // pairs kept in LDS (full: what the 64 KB of static LDS leave)
+    static constexpr int NCL = CAPB / 2;                                   // overlapping pairs gathered into tabB (uint32)
+};
+#define RT_BLOBS_REDO (-1)                // kp_n of a detection the small kernel left to the full one
+template <bool SMALL> struct RtBlobLds {
+    typedef RtBlobCap<SMALL> CP;
+    int16_t xy[2 * CP::NP];           // [row, col] in response order
+    int16_t idx[CP::NP];              // cKDTree.indices, later the aquicksort permutation
+    uint8_t lay[CP::NP];              // layer (1 | 2) in response order; 0 = pruned
+    BpNode nodes[CP::NNODE];
     int st[3 * 256];
     int bstack[3 * 64];
     BpTracker tr;
-    uint16_t tabA[2048];
-    alignas(8) uint16_t tabB[8192];   // hash table of the set order; before that the packed points of the tree build (2048 x 8 B)
-    uint32_t ovbits[(BP_LDS_PAIRS + 31) / 32 + 1];
-    uint32_t pl[RT_PL];               // the pairs, when they fit: the sequential set-order pass reads them one by one
+    uint16_t tabA[CP::CAPA];
+    alignas(8) uint16_t tabB[CP::CAPB];   // hash table of the set order; before that the packed points of the tree build (NP x 8 B)
+    uint32_t ovbits[(CP::LDS_PAIRS + 31) / 32 + 1];
+    uint32_t pl[CP::NPL];             // the pairs, when they fit: the sequential set-order pass reads them one by one
     int vals[8];
 };
 
+template <bool SMALL>
 __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
 {
-    __shared__ RtBlobLds L;
+    typedef RtBlobCap<SMALL> CP;
+    __shared__ RtBlobLds<SMALL> L;
     const int ls = blockIdx.x, slot = first + ls;
     if (slot >= *a.rt_n) return;
     const int lane = threadIdx.x;
     const int ncand = a.cand_n[ls];
+    if (!SMALL && a.kp_n[ls] != RT_BLOBS_REDO) return;                      // the small kernel did it
+    if (SMALL && ncand > CP::NP) {
+        if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
+        return;
+    }
     const int n = min(ncand, BP_MAX_PTS);
     const uint32_t *crc = a.cand_rc + (int64_t)ls * BP_MAX_PTS;
     const double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
@@ -829,7 +850,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
                 if (act) { start = L.nodes[me].start; end = L.nodes[me].end; p = bp_build_node(L.xy, pt, start, end, nd); }
                 const uint64_t bal = __ballot(act && p >= 0);
                 const int kids = 2 * __popcll(bal);
-                if (nn + kids > BP_MAX_NODES) { nn = -1; break; }              // (uniform)
+                if (nn + kids > CP::NNODE) { nn = -1; break; }                 // (uniform)
                 if (act) {
                     if (p >= 0) {
                         const int c0 = nn + 2 * __popcll(bal & ((1ull << lane) - 1ull));
@@ -847,6 +868,10 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         }
     }
     __syncthreads();
+    if (SMALL && nn < 0) {                                                   // more tree nodes than the small class holds: the full kernel's
+        if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
+        return;
+    }
     for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)(pt[i].v >> 32);          // cKDTree.indices
     __syncthreads();
     // dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
@@ -892,14 +917,18 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
             }
             const uint64_t bal = __ballot(ok);
             const int o = np + __popcll(bal & ((1ull << lane) - 1ull));
-            if (ok && o < BP_MAX_PAIRS) { pairs[o] = bp_pack(pi, pj); if (o < RT_PL) L.pl[o] = bp_pack(pi, pj); }
+            if (ok && o < BP_MAX_PAIRS) { pairs[o] = bp_pack(pi, pj); if (o < CP::NPL) L.pl[o] = bp_pack(pi, pj); }
             np += __popcll(bal);
         }
     }
     if (np > BP_MAX_PAIRS) { flags |= RT_F_PAIR_OVERFLOW; np = BP_MAX_PAIRS; }
     __syncthreads();
     // 4. which pairs overlap by more than 0.5 (original sigmas: a pair with a pruned member never changes anything)
-    const bool lds_set = np <= BP_LDS_PAIRS, lds_pl = np <= RT_PL;
+    if (SMALL && np > CP::LDS_PAIRS) {                                       // more pairs than the small set tables order: the full kernel's
+        if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
+        return;
+    }
+    const bool lds_set = np <= CP::LDS_PAIRS, lds_pl = np <= CP::NPL;
     uint32_t *ovb = lds_set ? L.ovbits : a.ovbits + (int64_t)ls * ((BP_MAX_PAIRS + 31) / 32 + 1);
     for (int w0 = 0; w0 < np; w0 += 64) {
         const int k = w0 + lane;
@@ -918,8 +947,8 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     uint16_t *order = a.order + (int64_t)ls * (BP_MAX_PAIRS + 1);
     if (lane == 0) {
         int m;
-        if (lds_pl) m = bp_pyset_order(L.pl, np, L.tabA, 2048, L.tabB, 8192, order);
-        else if (lds_set) m = bp_pyset_order(pairs, np, L.tabA, 2048, L.tabB, 8192, order);
+        if (lds_pl) m = bp_pyset_order(L.pl, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order);
+        else if (lds_set) m = bp_pyset_order(pairs, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order);
         else {
             uint16_t *big = a.bigtab + (int64_t)ls * 2 * 131072;
             m = bp_pyset_order(pairs, np, big, 131072, big + 131072, 131072, order);
@@ -944,12 +973,12 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         }
         const uint64_t bal = __ballot(ov);
         const int o = ncl + __popcll(bal & ((1ull << lane) - 1ull));
-        if (ov && o < 4096) cl[o] = pr;
+        if (ov && o < CP::NCL) cl[o] = pr;
         ncl += __popcll(bal);
     }
     __syncthreads();
     if (lane == 0) {
-        if (ncl <= 4096) {
+        if (ncl <= CP::NCL) {
             for (int k = 0; k < ncl; k++) {
                 const uint32_t pr = cl[k];
                 const int i = (int)(pr >> 16), j = (int)(pr & 0xffffu);
@@ -1083,7 +1112,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if (tr && (e = hipEventRecord(trace[2], st)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
-    hipLaunchKernelGGL(rt_blobs_kernel, dim3(B), dim3(64), 0, st, a, 0);
+    hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, a, 0);
+    hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, a, 0);
     e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rt_append_kernel, dim3(B), dim3(256), 0, st, a, 0);
