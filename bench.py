@@ -456,18 +456,6 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
     extra = {}
     if not args.dry_engine and not args.no_retrack and not args.h2d:
         stage_mix = eng.stage_times()
-        k2 = max(3, min(10, args.steps))
-        for en in engs:
-            en.set_retrack(0)                                   # no re-detection: the steady pair
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            step_all(s, False); s += 1
-        for en in engs:
-            en.synchronize()
-        extra["steady_pairs_per_s"] = round(B * k2 / (time.perf_counter() - t1), 1)
-        # (lanes are not re-seeded during the segment: the feature sets shrink, so the tracker does less work than in the mix)
-        extra["steady_mean_tracked"] = round(float(np.mean([en.results_array()["n_tracked"].mean() for en in engs])), 1)
         for en in engs:
             en.set_retrack(2)                                   # every lane re-detects: the cost of a retrack pair
         step_all(s, False); s += 1
@@ -476,6 +464,23 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         st_forced = eng.stage_times()
         extra["retrack_stage_ms_all_lanes"] = round(st_forced["retrack"], 3)
         extra["retrack_us_per_lane"] = round(st_forced["retrack"] * 1e3 / (B // len(engs)), 2)
+        # the steady pair: re-detection suspended after every lane has just re-detected; two untimed steps let the feature sets
+        # decay to the mix's level (~300 -> ~160 per lane), the next three are timed (`steady_mean_tracked`: features per lane in them)
+        for en in engs:
+            en.set_retrack(0)
+        for _ in range(2):
+            step_all(s, False); s += 1
+        barrier()
+        k2, trk = 3, []
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step_all(s, False); s += 1
+        for en in engs:
+            en.synchronize()
+        extra["steady_pairs_per_s"] = round(B * k2 / (time.perf_counter() - t1), 1)
+        for q in range(k2):
+            trk += [en.results_array(en.steps_enqueued() - 1 - q)["n_tracked"].mean() for en in engs]
+        extra["steady_mean_tracked"] = round(float(np.mean(trk)), 1)
         steady_ms = B / extra["steady_pairs_per_s"] * 1e3
         extra["retrack_pairs_per_s"] = round(B / ((steady_ms + st_forced["retrack"] * len(engs)) * 1e-3), 1)
         for en in engs:
