@@ -464,11 +464,11 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         st_forced = eng.stage_times()
         extra["retrack_stage_ms_all_lanes"] = round(st_forced["retrack"], 3)
         extra["retrack_us_per_lane"] = round(st_forced["retrack"] * 1e3 / (B // len(engs)), 2)
-        # the steady pair: re-detection suspended after every lane has just re-detected; two untimed steps let the feature sets
-        # decay to the mix's level (~300 -> ~160 per lane), the next three are timed (`steady_mean_tracked`: features per lane in them)
+        # the steady pair: re-detection suspended after every lane has just re-detected; one untimed step lets the feature sets
+        # decay to the mix's level (~300 -> ~170 per lane), the next three are timed (`steady_mean_tracked`: features per lane in them)
         for en in engs:
             en.set_retrack(0)
-        for _ in range(2):
+        for _ in range(1):
             step_all(s, False); s += 1
         barrier()
         k2, trk = 3, []
