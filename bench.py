@@ -465,13 +465,13 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         extra["retrack_stage_ms_all_lanes"] = round(st_forced["retrack"], 3)
         extra["retrack_us_per_lane"] = round(st_forced["retrack"] * 1e3 / (B // len(engs)), 2)
         # the steady pair: re-detection suspended after every lane has just re-detected; one untimed step lets the feature sets
-        # decay to the mix's level (~300 -> ~170 per lane), the next three are timed (`steady_mean_tracked`: features per lane in them)
+        # decay to the mix's level (~300 -> ~170 per lane), the next two are timed (`steady_mean_tracked`: features per lane in them)
         for en in engs:
             en.set_retrack(0)
         for _ in range(1):
             step_all(s, False); s += 1
         barrier()
-        k2, trk = 3, []
+        k2, trk = 2, []
         t1 = time.perf_counter()
         for _ in range(k2):
             step_all(s, False); s += 1
