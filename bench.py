@@ -228,8 +228,15 @@ def render_sequences(seeds, frames, md, work, procs):
     if procs == 1 or len(jobs) == 1:
         return [_render_sequence(j) for j in jobs]
     import multiprocessing as mp
-    with mp.get_context("spawn").Pool(procs) as pool:
-        return pool.map(_render_sequence, jobs)
+    pool = mp.get_context("spawn").Pool(procs)
+    try:
+        out = pool.map(_render_sequence, jobs)
+        pool.close()                                     # workers leave by themselves: no SIGTERM (a profiler's preloaded signal
+        pool.join()                                      # handler in the workers turned Pool.terminate() into a hang)
+        return out
+    except BaseException:
+        pool.terminate()
+        raise
 
 
 def run_rank(args):
@@ -653,10 +660,16 @@ def cpu_baseline(args, seqs, cyc):
         import multiprocessing as mp
         per = max(8, args.cpu_pairs // 4)
         jobs = [(5000 + i, args.frames, per, not args.no_md, not args.no_retrack) for i in range(nproc)]
-        with mp.get_context("spawn").Pool(nproc) as pool:
+        pool = mp.get_context("spawn").Pool(nproc)
+        try:
             w0 = time.perf_counter()
             done = pool.map(cpu_worker, jobs)
             wall = time.perf_counter() - w0
+            pool.close()
+            pool.join()
+        except BaseException:
+            pool.terminate()
+            raise
         # rate inside the timed loops (sequence rendering excluded): sum of pairs / longest loop
         cpu["all_cores"] = {"value": round(sum(p for p, _ in done) / max(t for _, t in done), 2), "unit": "scan-pairs/s", "cores": nproc,
                             "logical_cores_of_host": os.cpu_count(), "wall_s_incl_rendering": round(wall, 1),
@@ -678,8 +691,14 @@ def run_stream(args):
     poses = synth.poses_from_deltas(deltas)
     jobs = synth.stream_jobs(synth.StreamWorld(11, mover_fraction=0.15), poses, distortion=md, scintillation=0.4)
     import multiprocessing as mp
-    with mp.get_context("spawn").Pool(max(1, min(48, (os.cpu_count() or 2) // 2))) as pool:
+    pool = mp.get_context("spawn").Pool(max(1, min(48, (os.cpu_count() or 2) // 2)))
+    try:
         recs = pool.map(synth._render_job, jobs, chunksize=4)
+        pool.close()
+        pool.join()
+    except BaseException:
+        pool.terminate()
+        raise
     ctx = _ffi.Context(0)
     info = ctx.device_info()
     flags = {"rejectOutliers": True, "correctMotionDistortion": md}
