@@ -200,7 +200,7 @@ WORK_STEADY = dict(n_static=460, n_movers=24)
 
 def cpu_worker(job):
     """one independent oracle pipeline (N-core leg of the CPU baseline); returns (pairs, seconds)"""
-    seed, frames, pairs, md, retrack = job
+    seed, frames, pairs, md, retrack, new_seq = job
     import oracle
     from radarslampy_amd import synth
     recs, poses, feat = synth.make_sequence(seed, frames, distortion=md, **(WORK_RETRACK if retrack else WORK_STEADY))
@@ -210,9 +210,15 @@ def cpu_worker(job):
         feat = oracle.append_dedupe(np.empty((0, 2)), det(oracle.convertPolarImageToCartesian(recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.))))
     P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=md, detect=det)
     t0 = time.perf_counter()
+    done = 0
     for n in range(pairs):
-        P.step(recs[cyc[n % len(cyc)]])
-    return pairs, time.perf_counter() - t0
+        k = cyc[n % len(cyc)]
+        if retrack and new_seq and k == 0:
+            P.blobCoord = np.empty((0, 2), np.float32)         # a new sequence starts on frame 0 (like the GPU lanes): detection, no pair
+        else:
+            done += 1
+        P.step(recs[k])
+    return done, time.perf_counter() - t0
 
 
 def _render_sequence(job):
@@ -650,16 +656,22 @@ def cpu_baseline(args, seqs, cyc):
         feat = oracle.append_dedupe(np.empty((0, 2)), det(oracle.convertPolarImageToCartesian(recs[0][:, 11:11 + 2025].astype(np.float32) / np.float32(255.))))
     P = oracle.OdometryPipeline(recs[0], feat, poses[0], motion_distortion=not args.no_md, detect=det)
     c0 = time.perf_counter()
+    done = 0
     for n in range(args.cpu_pairs):
-        P.step(recs[cyc[n % len(cyc)]])
-    one = args.cpu_pairs / (time.perf_counter() - c0)
+        k = cyc[n % len(cyc)]
+        if det is not None and not args.endless and k == 0:
+            P.blobCoord = np.empty((0, 2), np.float32)         # a new sequence starts on frame 0 (like the GPU lanes): detection, no pair
+        else:
+            done += 1
+        P.step(recs[k])
+    one = done / (time.perf_counter() - c0)
     cpu = {"value": round(one, 3), "unit": "scan-pairs/s", "cores": 1, "kind": "port",
-           "sample": f"{args.cpu_pairs} consecutive scan pairs of synthetic sequence 0 (same workload incl. re-detections, oracle C/numpy restatement, 1 thread)"}
+           "sample": f"{args.cpu_pairs} consecutive scans of synthetic sequence 0 as a stream of finite sequences ({done} pairs; same workload incl. first-frame detections and re-detections, oracle C/numpy restatement, 1 thread)"}
     nproc = args.cpu_procs if args.cpu_procs >= 0 else max(1, (os.cpu_count() or 2) // 2)
     if nproc > 1:
         import multiprocessing as mp
         per = max(8, args.cpu_pairs // 4)
-        jobs = [(5000 + i, args.frames, per, not args.no_md, not args.no_retrack) for i in range(nproc)]
+        jobs = [(5000 + i, args.frames, per, not args.no_md, not args.no_retrack, not args.endless) for i in range(nproc)]
         pool = mp.get_context("spawn").Pool(nproc)
         try:
             w0 = time.perf_counter()
