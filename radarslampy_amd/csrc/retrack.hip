@@ -255,6 +255,33 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             } else if (bp * bh <= RI_BOX && cols >= 4) {
                 uint8_t *bx = box[wave];
                 const int sub = lane >> 4, c4 = (lane & 15) * 4;
+                const int nrg = (bh + 3) >> 2, ncb = (bp + 63) >> 6;       // pieces of 4 polar rows x 64 bytes, one load instruction each
+                if (mny >= 1 && mny - 1 + 4 * nrg <= rows && mnx + 64 * ncb <= cols) {
+                    // the box lies inside the scan with a margin: no azimuth wrap, no bin past the last one - a piece is "uniform base +
+                    // the lane's own offset" for the load and for the LDS store, and up to eight loads are in flight before the first
+                    // store (the general form below spends ~20 instructions per piece on clamps and addresses: a sixth of this kernel)
+                    const uint8_t *pl = p + (sub * stride + c4);
+                    uint8_t *bl = bx + (sub * bp + c4);
+                    const int npiece = nrg * ncb;
+                    for (int q0 = 0; q0 < npiece; q0 += 8) {
+                        uint32_t raw[8];
+                        int kg = (q0 / ncb) * 4, cb = (q0 % ncb) * 64;         // (wave-uniform)
+                        const int kg0 = kg, cb0 = cb;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (q0 + u < npiece) raw[u] = reinterpret_cast<const RtU32 *>(pl + ((mny - 1 + kg) * stride + mnx + cb))->v;
+                            cb += 64;
+                            if (cb >= bp) { cb = 0; kg += 4; }
+                        }
+                        kg = kg0; cb = cb0;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (q0 + u < npiece && sub < bh - kg && c4 < bp - cb) *reinterpret_cast<uint32_t *>(bl + (kg * bp + cb)) = raw[u];
+                            cb += 64;
+                            if (cb >= bp) { cb = 0; kg += 4; }
+                        }
+                    }
+                } else
                 for (int kg = 0; kg < bh; kg += 4) {
                     const int kk = kg + sub;
                     int r = mny + kk - 1;
@@ -345,26 +372,30 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                 const int C0 = g * 64 * RI_WAVES, ncols = min(64 * RI_WAVES, W - C0);
                 Tile *tg = tiles + ((band * RI_GROUPS + g) & 1) * RI_WAVES;
                 int j = 0;
-                if (ncols >= 8) {
-                    double x[8], y[8];
-                    {
-                        const double *q = &tg[0][lane][0];
+                if (ncols >= 16) {
+                    // two batches of eight columns in flight: while one is added up (eight dependent float64 additions) and written
+                    // back, the reads of the other have a whole batch to land (one batch ahead, every batch waited for its own LDS
+                    // round trip: 52 cycles per column)
+                    double xa[8], xb[8];
+                    auto rd = [&](double(&x)[8], int jj) {                 // (a batch never straddles two tiles: 64 = 8 x 8)
+                        const double *q = &tg[jj >> 6][lane][jj & 63];
 #pragma unroll
                         for (int u = 0; u < 8; u++) x[u] = q[u];
-                    }
-                    for (; j + 8 <= ncols; j += 8) {                       // a batch never straddles two tiles (64 = 8 x 8)
-                        double *q = &tg[j >> 6][lane][j & 63];
-                        if (j + 16 <= ncols) {                             // the next batch is read while this one is added up
-                            const double *qn = &tg[(j + 8) >> 6][lane][(j + 8) & 63];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) y[u] = qn[u];
-                        }
+                    };
+                    auto chain_wr = [&](double(&x)[8], int jj) {
 #pragma unroll
                         for (int u = 0; u < 8; u++) { carry = __dadd_rn(carry, x[u]); x[u] = carry; }
+                        double *q = &tg[jj >> 6][lane][jj & 63];
 #pragma unroll
                         for (int u = 0; u < 8; u++) q[u] = x[u];
-#pragma unroll
-                        for (int u = 0; u < 8; u++) x[u] = y[u];
+                    };
+                    rd(xa, 0);
+                    rd(xb, 8);
+                    for (; j + 16 <= ncols; j += 16) {
+                        chain_wr(xa, j);
+                        if (j + 24 <= ncols) rd(xa, j + 16);
+                        chain_wr(xb, j + 8);
+                        if (j + 32 <= ncols) rd(xb, j + 24);
                     }
                 }
                 for (; j < ncols; j++) {
