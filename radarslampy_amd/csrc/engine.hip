@@ -563,6 +563,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         // pitch of 2024 doubles HBM saw 1.44 x the bytes written)
         r.SP = (e->W + 15) & ~15;
         ok = ok && dalloc(ctx, e, &r.S, (size_t)r.SP * e->W * R);
+        ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.boxtab), retrack_boxtab_words(e->W));
         // candidate lists and bookkeeping tables per DETECTION (0.9 MB each): K4-K7 run once per step over all of them
         const size_t D = (size_t)B;
         ok = ok && dalloc(ctx, e, &r.cand_rc, D * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_val, D * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_n, D);
@@ -610,6 +611,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
                 if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     e->tr_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
+    if (e->rt_on) HIP_TRY(ctx, launch_retrack_boxtab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.boxtab)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
 }

@@ -13,6 +13,8 @@ struct RtArgs {
     // engine state
     const uint8_t *pool;
     const uint32_t *map;
+    const uint32_t *boxtab;         // per (band, group, column wave) of the one-sweep integral kernel: the polar footprint of the patch,
+                                    // {min ix | max ix << 16, min iy | max iy << 16} (max ix = 0xffff: nothing inside the maximum range)
     float *feat;
     int32_t *feat_n;
     const double *vel;
@@ -48,3 +50,6 @@ hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride,
                             const int32_t *n_active, int first);
 hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which);
 hipError_t retrack_init();
+// fills boxtab (retrack_boxtab_words(W) uint32 words) from the sampling map: geometry only, once per engine
+size_t retrack_boxtab_words(int W);
+hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *boxtab);

@@ -198,6 +198,29 @@ __device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict_
     return v;
 }
 
+// the polar footprint of every (band, group, wave) patch of the sweep depends on the sampling map only: computed once per engine
+// (one wave per patch, the reduction the integral kernel used to redo for every detection and phase: 24 cross-lane exchanges)
+__global__ __launch_bounds__(64) void rt_boxtab_kernel(const uint32_t *__restrict__ map, int W, int cols, uint32_t *__restrict__ boxtab)
+{
+    const int H = W, lane = threadIdx.x;
+    const int idx = blockIdx.x, wave = idx % RI_WAVES, g = (idx / RI_WAVES) % RI_GROUPS, band = idx / (RI_WAVES * RI_GROUPS);
+    const int c = min(g * 64 * RI_WAVES + 64 * wave + lane, W - 1);
+    int mnx = 0x7fffffff, mxx = -1, mny = 0x7fffffff, mxy = -1;
+    for (int k = 0; k < RI_ROWS; k++) {
+        const uint32_t m = map[(int64_t)min(band * RI_ROWS + k, H - 1) * W + c];
+        const int ix = m & 4095, iy = (m >> 12) & 1023;
+        if (ix < cols) { mnx = min(mnx, ix); mxx = max(mxx, ix); mny = min(mny, iy); mxy = max(mxy, iy); }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
+        mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
+    }
+    if (lane == 0) {
+        boxtab[2 * idx] = mxx < 0 ? 0xffff0000u : ((uint32_t)mnx | ((uint32_t)mxx << 16));
+        boxtab[2 * idx + 1] = mxx < 0 ? 0u : ((uint32_t)mny | ((uint32_t)mxy << 16));
+    }
+}
+
 __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs a, int first)
 {
     extern __shared__ double ri_lds[];
@@ -221,10 +244,13 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 #pragma unroll
         for (int g = 0; g < RI_GROUPS; g++) acc[g] = 0.0;
         uint32_t m[RI_ROWS];                                               // the map words of the NEXT A, in flight
+        uint32_t ext0 = 0, ext1 = 0;                                       // ... and its patch's polar footprint (boxtab)
         auto fetch = [&](int band, int g) {
             const int c = min(g * 64 * RI_WAVES + 64 * wave + lane, W - 1);
 #pragma unroll
             for (int k = 0; k < RI_ROWS; k++) m[k] = a.map[(int64_t)min(band * RI_ROWS + k, H - 1) * W + c];
+            const uint32_t *bt = a.boxtab + 2 * ((band * RI_GROUPS + g) * RI_WAVES + wave);
+            ext0 = bt[0]; ext1 = bt[1];
         };
         auto A = [&](int band, int g) {
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
@@ -235,19 +261,9 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             // the 4 taps per pixel become LDS byte reads; per-lane byte gathers from global memory (two 16-bit loads per pixel,
             // 32 wave-level gathers per phase) kept the texture addresser busy for 8 of this kernel's 19 us.  Patches whose box
             // does not fit (next to the image centre, across the 0 / 2 pi seam) gather as before.
-            int mnx = 0x7fffffff, mxx = -1, mny = 0x7fffffff, mxy = -1;
-#pragma unroll
-            for (int k = 0; k < RI_ROWS; k++) {
-                const int ix = m[k] & 4095, iy = (m[k] >> 12) & 1023;
-                if (ix < cols) { mnx = min(mnx, ix); mxx = max(mxx, ix); mny = min(mny, iy); mxy = max(mxy, iy); }
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                mnx = min(mnx, __shfl_xor(mnx, d)); mxx = max(mxx, __shfl_xor(mxx, d));
-                mny = min(mny, __shfl_xor(mny, d)); mxy = max(mxy, __shfl_xor(mxy, d));
-            }
-            mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);
-            mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
+            // extent of the patch's polar footprint: out of the table (the same for every detection), as wave-uniform values
+            const uint32_t e0 = __builtin_amdgcn_readfirstlane(ext0), e1 = __builtin_amdgcn_readfirstlane(ext1);
+            const int mnx = e0 & 0xffff, mxx = (e0 >> 16) == 0xffff ? -1 : (int)(e0 >> 16), mny = e1 & 0xffff, mxy = e1 >> 16;
             const int bw = mxx - mnx + 2, bh = mxy - mny + 2, bp = (bw + 3) & ~3;
             if (mxx < 0) {
 #pragma unroll
@@ -1106,6 +1122,15 @@ __global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
+size_t retrack_boxtab_words(int W) { return 2 * (size_t)((W + RI_ROWS - 1) / RI_ROWS) * RI_GROUPS * RI_WAVES; }
+
+hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *boxtab)
+{
+    if (W > 2048) return hipSuccess;                                       // (the one-sweep kernel is not used for such images)
+    hipLaunchKernelGGL(rt_boxtab_kernel, dim3((unsigned)(retrack_boxtab_words(W) / 2)), dim3(64), 0, st, map, W, cols, boxtab);
+    return hipGetLastError();
+}
+
 hipError_t retrack_init()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_det_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS_BYTES);
