@@ -406,3 +406,26 @@ def test_new_sequence_flag_restarts_a_lane_inside_the_step():
             assert not res[1]["retracked_on_device"]
     eng.close()
     ctx.close()
+
+
+def test_one_sweep_integral_kernel_on_a_small_image():
+    """208 first detections in one pass (>= 200: the one-sweep integral kernel with its footprint table, fast and general box
+    staging, the tail of the row chain) on a 300 x 300 image, lanes alternating between two scans: every lane's features equal the
+    oracle's"""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    clip, B = 300, 208
+    pay = [_blob_payload(clip, 7), np.ascontiguousarray(_blob_payload(clip, 7)[::-1])]
+    ctx = _ffi.Context(0)
+    eng = Engine(B, 2, ctx=ctx, rows=400, stride=clip, payload_off=0, clip=clip, retrack_on_device=True, retrack_slots=B)
+    for t in range(2):
+        eng.upload_scan(t, pay[t])
+    eng.init_lanes_detect(0, [b % 2 for b in range(B)], np.zeros((B, 3)))
+    want = []
+    for t in range(2):
+        cart = oracle.convertPolarImageToCartesian(pay[t].astype(np.float32) / np.float32(255.))
+        want.append(oracle.append_dedupe(np.empty((0, 2)), _detect(cart)))
+    for b in (0, 1, 2, 101, 206, 207):
+        assert np.array_equal(eng.lane_features(b), want[b % 2]), b
+    eng.close()
+    ctx.close()
