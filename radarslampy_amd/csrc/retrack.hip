@@ -500,6 +500,13 @@ __device__ __forceinline__ double sd_box(double a, double d, double b, double c)
     asm("v_add_f64 %0, %1, -%2 clamp" : "=v"(r) : "v"(t), "v"(c));
     return r;
 }
+// max of two determinants (never NaN): one v_max_f64 - fmax() canonicalises both operands first (three instructions)
+__device__ __forceinline__ double sd_max(double x, double y)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 template <int SIZE> __device__ __forceinline__ double sd_wi() { return __dmul_rn(__ddiv_rn(__ddiv_rn(1.0, (double)SIZE), (double)SIZE), SD_UNSCALE); }
 
 __device__ __forceinline__ double sd_ldr(const uint32_t (&ca)[12], const uint32_t (&cb)[12], int row, int j)
@@ -752,14 +759,14 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
 #pragma unroll
         for (int k = 0; k < SD_T / 8; k++) {
             const int rr = 8 * k + w8, r = rbase + rr;
-            double mx = fmax(d0[k], d1[k]);
+            double mx = sd_max(d0[k], d1[k]);
             if (mx > thr) {
                 // (rare) the dxy term, hessian_det_pruned's second half.  A product that stays at or below the threshold can neither
                 // pass nor exceed a passing neighbour, so it goes to the maxima buffer as it is
                 if (d0[k] > thr) d0[k] = sd_dxy<15>(d0[k], r, c, H, W, cbase);
                 if (d1[k] > thr) d1[k] = sd_dxy<30>(d1[k], r, c, H, W, cbase);
                 if (!cvalid) { d0[k] = 0.0; d1[k] = 0.0; }                 // outside the image: nothing that could exceed a maximum
-                mx = fmax(d0[k], d1[k]);
+                mx = sd_max(d0[k], d1[k]);
                 if (mx > thr) cand |= 1u << k;
             }
             if (k == SD_T / 8 - 1 && w8 >= 6) m2at(WB, rr - (SD_T - 2), 0) = m2at(WB ^ 1, 2 + rr, 0);   // the seam: the last two rows of the step before
