@@ -174,7 +174,10 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8)
 struct __attribute__((packed)) RtU16 { uint16_t v; };
 struct __attribute__((packed)) RtU32 { uint32_t v; };
-#define RI_BOX 1536                        // bytes of polar footprint a column wave may stage (rt_integral_kernel)                      // two neighbouring codes in one (unaligned) load
+#ifndef RI_BOX
+#define RI_BOX 1536
+#endif
+//                        // bytes of polar footprint a column wave may stage (rt_integral_kernel)                      // two neighbouring codes in one (unaligned) load
 __device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict__ p, int rows, int cols, int stride, const float *lut)
 {
     const int ix = m & 4095, iy = (m >> 12) & 1023;
