@@ -3,6 +3,7 @@
 #include "roam_internal.h"
 #include "blobprune.h"
 
+#define RT_TWO_PASS_SLOTS 200     // = RI_MIN_DETECTIONS of retrack.hip: chunks of at least that many detections take the one-sweep kernel
 enum { RT_F_CAND_OVERFLOW = 1, RT_F_TREE_OVERFLOW = 2, RT_F_PAIR_OVERFLOW = 4, RT_F_FEAT_OVERFLOW = 8 };
 
 struct RtArgs {
@@ -24,6 +25,7 @@ struct RtArgs {
     int32_t *rt_n, *rt_lane, *rt_scan;
     // per-slot scratch (slots entries): the image-scale kernels work on chunks of `slots` detections
     double *S;                      // W rows x SP float64: integral image, rows padded to whole 128-byte lines
+    double *colT;                   // two-pass integral image (small chunks): ceil(W / 64) band totals x W columns, RT_TWO_PASS_SLOTS slots
     int SP;                         // row pitch of S in elements (a multiple of 16, >= W)
     // per-detection scratch (one entry per lane: the bookkeeping kernels run once over all detections of a step)
     uint32_t *cand_rc;              // BP_MAX_PTS: row << 16 | col << 2 | layer (appended by the determinant kernel, sorted by rt_emit_kernel)

@@ -72,14 +72,20 @@ __device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dm
 //   * rt_integ_cols_kernel + rt_integ_rows_kernel: thousands of threads per detection, three times the traffic - 47 us per detection
 //     at scale, 1.7 ms for one alone
 // Both are launched; the one whose regime it is not returns at once.
-#define RI_MIN_DETECTIONS 200
+#define RI_MIN_DETECTIONS RT_TWO_PASS_SLOTS
 __device__ __forceinline__ bool rt_one_sweep(const RtArgs &a, int first) { return a.W <= 2048 && *a.rt_n - first >= RI_MIN_DETECTIONS; }
 
+// Column pass, parallel over bands of RC_BAND rows.  A pixel is a float32 of at least 2^-18 (code / 255 times a weight product that is a
+// multiple of 2^-10) or zero, i.e. a multiple of 2^-41, and a column of at most 4094 of them sums to less than 2^12: every partial
+// sum is EXACT in float64, in any order.  So a thread adds up its column inside one band only (a chain of 64 instead of 2024 rows:
+// this pass was 1.0 of the 2.8 ms of a lone detection), writes the band-local sums and the band's total; rt_integ_colfix_kernel
+// turns the totals into what lies above each band, and the row pass adds that in as it loads (all exact = NumPy's values).
+#define RC_BAND 64
 __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 {
-    const int ls = blockIdx.y, slot = first + ls;
+    const int ls = blockIdx.z, slot = first + ls;
     if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
-    const int c = blockIdx.x * 256 + threadIdx.x, W = a.W;
+    const int c = blockIdx.x * 256 + threadIdx.x, W = a.W, band = blockIdx.y, nb = (W + RC_BAND - 1) / RC_BAND;
     if (c >= W) return;
     const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
     double *S = a.S + (int64_t)ls * a.SP * W;
@@ -104,8 +110,9 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
         return v;
     };
     // four rows per iteration: their map words and taps are independent loads, only the four additions are a chain
-    int r = 0;
-    for (; r + 4 <= W; r += 4) {
+    int r = band * RC_BAND;
+    const int rend = min(r + RC_BAND, W);
+    for (; r + 4 <= rend; r += 4) {
         uint32_t m[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) m[k] = a.map[(int64_t)(r + k) * W + c];
@@ -115,7 +122,20 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 #pragma unroll
         for (int k = 0; k < 4; k++) { acc = __dadd_rn(acc, (double)v[k]); S[(int64_t)(r + k) * a.SP + c] = acc; }
     }
-    for (; r < W; r++) { acc = __dadd_rn(acc, (double)pixel(a.map[(int64_t)r * W + c])); S[(int64_t)r * a.SP + c] = acc; }
+    for (; r < rend; r++) { acc = __dadd_rn(acc, (double)pixel(a.map[(int64_t)r * W + c])); S[(int64_t)r * a.SP + c] = acc; }
+    a.colT[((int64_t)ls * nb + band) * W + c] = acc;
+}
+
+// band totals -> sum of the bands above (exclusive prefix per column; exact, see above)
+__global__ __launch_bounds__(256) void rt_integ_colfix_kernel(RtArgs a, int first)
+{
+    const int ls = blockIdx.y, slot = first + ls;
+    if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, W = a.W, nb = (W + RC_BAND - 1) / RC_BAND;
+    if (c >= W) return;
+    double *T = a.colT + (int64_t)ls * nb * W + c;
+    double run = 0.0;
+    for (int b = 0; b < nb; b++) { const double t = T[(int64_t)b * W]; T[(int64_t)b * W] = run; run = __dadd_rn(run, t); }
 }
 
 // one wavefront per 64 rows: lane = row, sequential along the row (the reference's summation order); the image streams
@@ -125,30 +145,44 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 #endif
 __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 {
+    static_assert(RC_BAND == 64, "a workgroup of this kernel is one band of the column pass");
     __shared__ double tile[64][RT_CW + 1];
     const int ls = blockIdx.y, slot = first + ls;
     if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
-    const int W = a.W, H = a.W;
+    const int W = a.W, H = a.W, nb = (W + RC_BAND - 1) / RC_BAND;
     double *S = a.S + (int64_t)ls * a.SP * W;
+    const double *T = a.colT + ((int64_t)ls * nb + blockIdx.x) * W;   // column sums of the bands above this one
     const int lane = threadIdx.x, r0 = blockIdx.x * 64;
     constexpr int RPI = 64 / RT_CW;                     // rows per load instruction
+    constexpr int NLD = 64 / RPI;                       // loads per lane and tile
     const int lr = lane / RT_CW, lc = lane % RT_CW;
     double acc = 0;
+    // the next tile's loads are in flight while this tile's chain runs (a lone detection waited for 64 round trips to HBM here)
+    double nxt[NLD], off = 0.0, offn = 0.0;
+    auto fetch = [&](int c0) {
+        const int c = c0 + lc;
+        offn = c < W ? T[c] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int r = r0 + k * RPI + lr;
+            nxt[k] = (r < H && c < W) ? S[(int64_t)r * a.SP + c] : 0.0;
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < W; c0 += RT_CW) {
         const int c = c0 + lc;
-#pragma unroll 8
-        for (int k = 0; k < 64; k += RPI) {
-            const int r = r0 + k + lr;
-            tile[k + lr][lc] = (r < H && c < W) ? S[(int64_t)r * a.SP + c] : 0.0;
-        }
+        off = offn;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) tile[k * RPI + lr][lc] = __dadd_rn(nxt[k], off);
         __syncthreads();
+        if (c0 + RT_CW < W) fetch(c0 + RT_CW);
         const int nc = min(RT_CW, W - c0);
         for (int j = 0; j < nc; j++) { acc = __dadd_rn(acc, tile[lane][j]); tile[lane][j] = acc; }
         __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < 64; k += RPI) {
-            const int r = r0 + k + lr;
-            if (r < H && c < W) S[(int64_t)r * a.SP + c] = tile[k + lr][lc];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int r = r0 + k * RPI + lr;
+            if (r < H && c < W) S[(int64_t)r * a.SP + c] = tile[k * RPI + lr][lc];
         }
         __syncthreads();
     }
@@ -1171,8 +1205,11 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         const bool tr = trace && first == 0;
         if (tr && (e = hipEventRecord(trace[0], st)) != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, first);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, first);
+        // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
+        const int P2 = min(P, RT_TWO_PASS_SLOTS);
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, first);
         if (tr && (e = hipEventRecord(trace[1], st)) != hipSuccess) return e;
         if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(trace[2], st)) != hipSuccess) return e;
@@ -1199,8 +1236,10 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
     const int W = a.W;
     if (which == 0) {
         hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, P), dim3(256), 0, st, a, 0);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P), dim3(64), 0, st, a, 0);
+        const int P2 = min(P, RT_TWO_PASS_SLOTS);
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, 0);
     } else {
         hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
         if (e != hipSuccess) return e;
