@@ -12,10 +12,13 @@
 #include "roam_internal.h"
 
 #define SSC_BITMAP_BYTES 65536
+// the batched (engine) launch asks for a quarter of that: four square widths out of five of a 2024 x 2024 image need less than 1 KB of
+// cell bitmap, and with 64 KB only two problems fit a CU (the pairwise form takes over below a width of ~11 px - same result)
+#define SSC_BATCH_BITMAP_BYTES 16384
 
 __device__ __forceinline__ void ssc_body(const double *__restrict__ kp, int B, int num_ret, double tol, int cols, int rows,
                                          int32_t *__restrict__ work, int32_t *__restrict__ sel, int32_t *__restrict__ n_sel,
-                                         uint32_t *bitmap)
+                                         uint32_t *bitmap, int bitmap_bytes)
 {
     const int lane = threadIdx.x;
     int32_t *resA = work, *resB = work + B, *accr = work + 2 * (size_t)B, *accq = work + 3 * (size_t)B;
@@ -41,7 +44,7 @@ __device__ __forceinline__ void ssc_body(const double *__restrict__ kp, int B, i
         const double c = width / 2;
         const int w = (int)floor(width / c);
         const double ncd = floor(cols / c), nrd = floor(rows / c);
-        const bool grid_mode = (ncd + 1) * (nrd + 1) <= (double)SSC_BITMAP_BYTES * 8;
+        const bool grid_mode = (ncd + 1) * (nrd + 1) <= (double)bitmap_bytes * 8;
         const int ncols = (int)ncd + 1, nrows = (int)nrd + 1;
         if (grid_mode) {
             const int nwords = (ncols * nrows + 31) / 32;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(64) void ssc_kernel(const double *__restrict__ kp, 
                                                  int32_t *__restrict__ sel, int32_t *__restrict__ n_sel)
 {
     extern __shared__ uint32_t bitmap[];
-    ssc_body(kp, B, num_ret, tol, cols, rows, work, sel, n_sel, bitmap);
+    ssc_body(kp, B, num_ret, tol, cols, rows, work, sel, n_sel, bitmap, SSC_BITMAP_BYTES);
 }
 
 // batched: problem p = blockIdx.x (skipped when first + p >= *n_active): kp + p * kp_stride (rows of 3 doubles), count[p]
@@ -131,14 +134,14 @@ __global__ __launch_bounds__(64) void ssc_batch_kernel(const double *__restrict_
     const int B = min(count[p], kp_cap);
     if (B <= 0) { if (threadIdx.x == 0) n_sel[p] = 0; return; }
     ssc_body(kp + (int64_t)p * kp_stride, B, num_ret, tol, cols, rows, work + (int64_t)p * 4 * kp_cap, sel + (int64_t)p * kp_cap,
-             n_sel + p, bitmap);
+             n_sel + p, bitmap, SSC_BATCH_BITMAP_BYTES);
 }
 
 hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride, const int32_t *count, int kp_cap, int P,
                             int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
                             const int32_t *n_active, int first)
 {
-    hipLaunchKernelGGL(ssc_batch_kernel, dim3(P), dim3(64), SSC_BITMAP_BYTES, st, kp, kp_stride, count, kp_cap, num_ret, tol, cols,
+    hipLaunchKernelGGL(ssc_batch_kernel, dim3(P), dim3(64), SSC_BATCH_BITMAP_BYTES, st, kp, kp_stride, count, kp_cap, num_ret, tol, cols,
                        rows, work, sel, n_sel, n_active, first);
     return hipGetLastError();
 }
