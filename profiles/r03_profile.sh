@@ -17,11 +17,13 @@ timeout 600 python bench.py --endless --preroll 0 --distinct 4 --steps 20 --warm
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 20 --warmup 5 --cpu-pairs 0 --render-procs 1 > $O/bench_default_under_rocprof.json 2> $O/prof.log
 cp $O/prof/*/*kernel_stats.csv $O/kernel_stats.csv
 python3 profiles/trace_summary.py $O/prof > $O/kernel_trace_summary.csv 2>/dev/null
+python3 profiles/timeline_mix.py $O/prof > $O/step_timeline.txt 2>/dev/null
 rm -f $O/prof/*/*kernel_trace.csv          # tens of MB; the summaries above are what gets committed
 timeout 600 python bench.py --stream > $O/bench_stream_md_on.json 2> $O/bench_stream_md_on.err
 timeout 600 python bench.py --stream --no-md > $O/bench_stream_md_off.json 2> $O/bench_stream_md_off.err
 timeout 600 python bench.py --h2d --lanes 1024 --cpu-pairs 0 > $O/bench_h2d_streaming.json 2> $O/bench_h2d.err
 timeout 600 python profiles/run_full_seq.py 8866 1 > $O/full_seq_1_md_on.json 2> $O/full_seq_on.err
 timeout 600 python profiles/run_full_seq.py 8866 0 > $O/full_seq_1_md_off.json 2> $O/full_seq_off.err
+bash profiles/one_detection_trace.sh > $O/one_detection_trace.txt 2>&1
 for f in $O/bench_default_20_5.json $O/bench_default_50_3.json $O/bench_round2_workload_20_5.json $O/bench_h2d_streaming.json; do cut -c1-200 $f; done
 cat $O/full_seq_1_md_on.json $O/full_seq_1_md_off.json; head -12 $O/kernel_stats.csv | cut -d, -f1-5
