@@ -1,7 +1,8 @@
 // doh_common.h - device functions shared by the stage-level DoH kernels (doh.hip) and the engine's retrack (retrack.hip):
 // the box-filter Hessian determinant of skimage's _hessian_matrix_det, operation by operation (oracle/c/doh.c).
-// The integral image is read through an accessor so that the same arithmetic runs on global memory (indices clipped at
-// the image border like skimage's _integ) and on a tile staged in LDS (interior tiles: nothing to clip).
+// The integral image is read through an accessor (indices clipped at the image border like skimage's _integ).  hessian_box /
+// hessian_det_pruned below are the box layouts and the pruning rule that retrack.hip's strip-march kernel (rt_det_strip_kernel)
+// implements with its own LDS addressing: its comments refer to them.
 #pragma once
 #include "roam_internal.h"
 
@@ -12,22 +13,6 @@ struct DohGlobalAcc {
     __device__ __forceinline__ int cr(int r) const { return clipi(r, 0, H - 1); }
     __device__ __forceinline__ int cc(int c) const { return clipi(c, 0, W - 1); }
     __device__ __forceinline__ double at(int r, int c) const { return S[(int64_t)r * W + c]; }
-};
-
-template <int PITCH>
-struct DohLdsAcc {                       // rows rbase.., columns cbase.. of the integral image, staged by the caller
-    const double *blk; int rbase, cbase;
-    __device__ __forceinline__ int cr(int r) const { return r; }
-    __device__ __forceinline__ int cc(int c) const { return c; }
-    __device__ __forceinline__ double at(int r, int c) const { return blk[(r - rbase) * PITCH + (c - cbase)]; }
-};
-
-template <int PITCH>
-struct DohLdsClipAcc {                   // a staged block next to the image border: indices clipped like skimage's _integ, then read from LDS
-    const double *blk; int rbase, cbase, H, W;
-    __device__ __forceinline__ int cr(int r) const { return clipi(r, 0, H - 1); }
-    __device__ __forceinline__ int cc(int c) const { return clipi(c, 0, W - 1); }
-    __device__ __forceinline__ double at(int r, int c) const { return blk[(r - rbase) * PITCH + (c - cbase)]; }
 };
 
 template <typename ACC>
