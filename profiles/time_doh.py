@@ -21,7 +21,7 @@ for b in range(B):
     eng.init_lane(b, b * 2, feat[:40], poses[0])
 eng.step(np.arange(B, dtype=np.int32) * 2 + 1)
 eng.synchronize()
-for k in ("doh_integral", "doh_det_maxima"):
+for k in os.environ.get("KERNELS", "doh_integral,doh_det_maxima").split(","):
     ms, by = eng.time_kernel(k, 3)
     print(f"{k}: {ms:.2f} ms per {B} detections = {ms*1e3/B:.1f} us each, {by/ms/1e6:.0f} GB/s algorithmic")
 eng.close(); ctx.close()

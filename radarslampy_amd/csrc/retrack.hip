@@ -203,13 +203,21 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #ifndef RI_ROWS
 #define RI_ROWS 16
 #endif
+#ifndef RI_WAVES
 #define RI_WAVES 4
+#endif
 #define RI_GROUPS (2048 / (64 * RI_WAVES))
-#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8)
+#ifndef RI_LDS_PAD
+#define RI_LDS_PAD 0                        // (occupancy experiments: profiles/build_variant.py)
+#endif
+#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
 struct __attribute__((packed)) RtU16 { uint16_t v; };
 struct __attribute__((packed)) RtU32 { uint32_t v; };
 #ifndef RI_BOX
 #define RI_BOX 1536
+#endif
+#ifndef RI_PREFETCH
+#define RI_PREFETCH 1                       // the box of the next phase is loaded one phase ahead (rt_integral_kernel)
 #endif
 //                        // bytes of polar footprint a column wave may stage (rt_integral_kernel)                      // two neighbouring codes in one (unaligned) load
 __device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict__ p, int rows, int cols, int stride, const float *lut)
@@ -281,13 +289,65 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 #pragma unroll
         for (int g = 0; g < RI_GROUPS; g++) acc[g] = 0.0;
         uint32_t m[RI_ROWS];                                               // the map words of the NEXT A, in flight
-        uint32_t ext0 = 0, ext1 = 0;                                       // ... and its patch's polar footprint (boxtab)
+        uint32_t ext0 = 0, ext1 = 0;                                       // the polar footprint (boxtab) of the patch of the A after the next, in flight
+        uint32_t cur0 = 0xffff0000u, cur1 = 0;                             // ... of the next A (wave-uniform)
+        uint32_t raw[8];                                                   // the first eight pieces of the next A's box, in flight (RI_PREFETCH)
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         auto fetch = [&](int band, int g) {
             const int c = min(g * 64 * RI_WAVES + 64 * wave + lane, W - 1);
 #pragma unroll
             for (int k = 0; k < RI_ROWS; k++) m[k] = a.map[(int64_t)min(band * RI_ROWS + k, H - 1) * W + c];
-            const uint32_t *bt = a.boxtab + 2 * ((band * RI_GROUPS + g) * RI_WAVES + wave);
+        };
+        auto fetch_ext = [&](int i) {
+            const uint32_t *bt = a.boxtab + 2 * (i * RI_WAVES + wave_u);
             ext0 = bt[0]; ext1 = bt[1];
+        };
+        // geometry of a patch's polar box out of its table entry (all wave-uniform)
+        struct Box { int mnx, mxx, mny, mxy, bh, bp, nrg, ncb; bool staged, inside; };
+        auto geom = [&](uint32_t e0, uint32_t e1) {
+            Box b;
+            b.mnx = e0 & 0xffff; b.mxx = (e0 >> 16) == 0xffff ? -1 : (int)(e0 >> 16); b.mny = e1 & 0xffff; b.mxy = e1 >> 16;
+            const int bw = b.mxx - b.mnx + 2;
+            b.bh = b.mxy - b.mny + 2; b.bp = (bw + 3) & ~3;
+            b.nrg = (b.bh + 3) >> 2; b.ncb = (b.bp + 63) >> 6;             // pieces of 4 polar rows x 64 bytes, one load instruction each
+            b.staged = b.mxx >= 0 && b.bp * b.bh <= RI_BOX && cols >= 4;
+            // the box lies inside the scan with a margin: no azimuth wrap, no bin past the last one
+            b.inside = b.staged && b.mny >= 1 && b.mny - 1 + 4 * b.nrg <= rows && b.mnx + 64 * b.ncb <= cols;
+            return b;
+        };
+        const int sub = lane >> 4, c4 = (lane & 15) * 4;
+        // pieces q0 .. q0 + 7 of an `inside` box: a piece is "uniform base + the lane's own offset" for the load and for the LDS store
+        auto load_pieces = [&](const Box &b, int q0) {
+            const uint8_t *pl = p + (sub * stride + c4);
+            const int npiece = b.nrg * b.ncb;
+            int kg = (q0 / b.ncb) * 4, cb = (q0 % b.ncb) * 64;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (q0 + u < npiece) raw[u] = reinterpret_cast<const RtU32 *>(pl + ((b.mny - 1 + kg) * stride + b.mnx + cb))->v;
+                cb += 64;
+                if (cb >= b.bp) { cb = 0; kg += 4; }
+            }
+        };
+        auto store_pieces = [&](const Box &b, int q0, uint8_t *bx) {
+            uint8_t *bl = bx + (sub * b.bp + c4);
+            const int npiece = b.nrg * b.ncb;
+            int kg = (q0 / b.ncb) * 4, cb = (q0 % b.ncb) * 64;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (q0 + u < npiece && sub < b.bh - kg && c4 < b.bp - cb) *reinterpret_cast<uint32_t *>(bl + (kg * b.bp + cb)) = raw[u];
+                cb += 64;
+                if (cb >= b.bp) { cb = 0; kg += 4; }
+            }
+        };
+        // The first eight pieces of the NEXT A's box leave one phase ahead (its extent came out of the table a phase before that): their
+        // HBM / L2 round trip - 37 % of a column wave's time when the loads were issued inside the phase that needs them (s_memtime) -
+        // passes while the row wave works on the tile in between
+        auto prefetch_box = [&]() {
+            cur0 = __builtin_amdgcn_readfirstlane(ext0); cur1 = __builtin_amdgcn_readfirstlane(ext1);
+#if RI_PREFETCH
+            const Box b = geom(cur0, cur1);
+            if (b.inside) load_pieces(b, 0);
+#endif
         };
         auto A = [&](int band, int g) {
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
@@ -299,40 +359,19 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             // 32 wave-level gathers per phase) kept the texture addresser busy for 8 of this kernel's 19 us.  Patches whose box
             // does not fit (next to the image centre, across the 0 / 2 pi seam) gather as before.
             // extent of the patch's polar footprint: out of the table (the same for every detection), as wave-uniform values
-            const uint32_t e0 = __builtin_amdgcn_readfirstlane(ext0), e1 = __builtin_amdgcn_readfirstlane(ext1);
-            const int mnx = e0 & 0xffff, mxx = (e0 >> 16) == 0xffff ? -1 : (int)(e0 >> 16), mny = e1 & 0xffff, mxy = e1 >> 16;
-            const int bw = mxx - mnx + 2, bh = mxy - mny + 2, bp = (bw + 3) & ~3;
-            if (mxx < 0) {
+            const Box b = geom(cur0, cur1);
+            const int mnx = b.mnx, mny = b.mny, bh = b.bh, bp = b.bp;
+            if (b.mxx < 0) {
 #pragma unroll
                 for (int k = 0; k < RI_ROWS; k++) v[k] = 0.f;              // beyond the maximum range
-            } else if (bp * bh <= RI_BOX && cols >= 4) {
+            } else if (b.staged) {
                 uint8_t *bx = box[wave];
-                const int sub = lane >> 4, c4 = (lane & 15) * 4;
-                const int nrg = (bh + 3) >> 2, ncb = (bp + 63) >> 6;       // pieces of 4 polar rows x 64 bytes, one load instruction each
-                if (mny >= 1 && mny - 1 + 4 * nrg <= rows && mnx + 64 * ncb <= cols) {
-                    // the box lies inside the scan with a margin: no azimuth wrap, no bin past the last one - a piece is "uniform base +
-                    // the lane's own offset" for the load and for the LDS store, and up to eight loads are in flight before the first
-                    // store (the general form below spends ~20 instructions per piece on clamps and addresses: a sixth of this kernel)
-                    const uint8_t *pl = p + (sub * stride + c4);
-                    uint8_t *bl = bx + (sub * bp + c4);
-                    const int npiece = nrg * ncb;
+                if (b.inside) {
+                    // (the general form below spends ~20 instructions per piece on clamps and addresses: a sixth of this kernel)
+                    const int npiece = b.nrg * b.ncb;
                     for (int q0 = 0; q0 < npiece; q0 += 8) {
-                        uint32_t raw[8];
-                        int kg = (q0 / ncb) * 4, cb = (q0 % ncb) * 64;         // (wave-uniform)
-                        const int kg0 = kg, cb0 = cb;
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            if (q0 + u < npiece) raw[u] = reinterpret_cast<const RtU32 *>(pl + ((mny - 1 + kg) * stride + mnx + cb))->v;
-                            cb += 64;
-                            if (cb >= bp) { cb = 0; kg += 4; }
-                        }
-                        kg = kg0; cb = cb0;
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            if (q0 + u < npiece && sub < bh - kg && c4 < bp - cb) *reinterpret_cast<uint32_t *>(bl + (kg * bp + cb)) = raw[u];
-                            cb += 64;
-                            if (cb >= bp) { cb = 0; kg += 4; }
-                        }
+                        if (q0 > 0 || !RI_PREFETCH) load_pieces(b, q0);
+                        store_pieces(b, q0, bx);
                     }
                 } else
                 for (int kg = 0; kg < bh; kg += 4) {
@@ -344,9 +383,9 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                         if (kk < bh && cc < bp) {
                             // bytes beyond the scan's last range bin read as zero: the load is moved back inside the row and shifted
                             const int x0 = mnx + cc, xl = min(x0, cols - 4), sh = 8 * (x0 - xl);
-                            uint32_t raw = 0;
-                            if (sh < 32) raw = reinterpret_cast<const RtU32 *>(p + r * stride + xl)->v >> sh;
-                            *reinterpret_cast<uint32_t *>(bx + kk * bp + cc) = raw;
+                            uint32_t rw = 0;
+                            if (sh < 32) rw = reinterpret_cast<const RtU32 *>(p + r * stride + xl)->v >> sh;
+                            *reinterpret_cast<uint32_t *>(bx + kk * bp + cc) = rw;
                         }
                     }
                 }
@@ -372,7 +411,14 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                 for (int k = 0; k < RI_ROWS; k++) v[k] = rt_pixel(m[k], p, rows, cols, stride, lut);
             }
             // the next phase's map words leave now; they land while the row wave works
-            if (g + 1 < RI_GROUPS) fetch(band, g + 1); else if (band + 1 < nbands) fetch(band + 1, 0);
+            {
+                const int i1 = band * RI_GROUPS + g + 1;
+                if (i1 < nbands * RI_GROUPS) {
+                    fetch(i1 / RI_GROUPS, i1 % RI_GROUPS);
+                    prefetch_box();
+                    if (i1 + 1 < nbands * RI_GROUPS) fetch_ext(i1 + 1);
+                }
+            }
             {
                 // acc[0] is always the running sum of the CURRENT group's column: the groups come round in order, so the array is
                 // rotated by one after every phase (8 register moves; a group-indexed array was kept in scratch memory by the
@@ -403,9 +449,12 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                     for (int k = 0; k < nk; k++) q[(int64_t)k * SP] = tl[k][lane];
             }
         };
-        fetch(0, 0);
-        A(0, 0);
         const int nphase = nbands * RI_GROUPS;
+        fetch(0, 0);
+        fetch_ext(0);
+        prefetch_box();
+        if (nphase > 1) fetch_ext(1);
+        A(0, 0);
 #pragma unroll 1
         for (int i = 0; i < nphase; i++) {
             __syncthreads();                                               // A(i) and B(i-1) are complete
@@ -521,7 +570,10 @@ __device__ __forceinline__ void rt_push_maxima(const RtArgs &a, int ls, int r, i
 #define SD_THREADS (512 * SD_HALVES)
 #define SD_RING_BYTES ((SD_RING + SD_DUP) * SD_PITCHB)
 #define SD_M2_ROWS (SD_T + 2)
-#define SD_LDS_BYTES (SD_RING_BYTES + 2 * SD_M2_ROWS * SD_PC * 8)
+#ifndef SD_LDS_PAD
+#define SD_LDS_PAD 0
+#endif
+#define SD_LDS_BYTES (SD_RING_BYTES + 2 * SD_M2_ROWS * SD_PC * 8 + SD_LDS_PAD)
 #define SD_NST ((SD_T * SD_BP + SD_THREADS - 1) / SD_THREADS)   // staged elements per thread and step (3)
 extern __shared__ __align__(16) char sd_smem[];
 
