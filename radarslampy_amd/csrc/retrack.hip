@@ -66,11 +66,10 @@ __global__ __launch_bounds__(256) void rt_collect_kernel(const roam_lane_result 
 __device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dmul_rn((double)k, 1.0 / 255.0); }
 
 // Two ways to the integral image, chosen on the device by the number of detections of the chunk (only the device knows it):
-//   * rt_integral_kernel (below): one workgroup per detection, the image written once - 19 us per detection at 512, but a chain of
-//     1016 dependent phases per detection: 9.7 ms per chunk whatever its size (measured also with taps and map words prefetched one
-//     and two phases ahead: no gain - the byte gathers are bound by the texture addresser's throughput, not by latency)
-//   * rt_integ_cols_kernel + rt_integ_rows_kernel: thousands of threads per detection, three times the traffic - 47 us per detection
-//     at scale, 1.7 ms for one alone
+//   * rt_integral_kernel (below): one workgroup per detection, the image written once - 12.7 us per detection at 512, but a chain of
+//     1016 dependent phases per detection: 6.5 ms per chunk whatever its size
+//   * rt_integ_cols_kernel + rt_integ_colfix_kernel + rt_integ_rows_kernel: thousands of threads per detection, three times the
+//     traffic, 0.26 ms for one alone
 // Both are launched; the one whose regime it is not returns at once.
 #define RI_MIN_DETECTIONS RT_TWO_PASS_SLOTS
 __device__ __forceinline__ bool rt_one_sweep(const RtArgs &a, int first) { return a.W <= 2048 && *a.rt_n - first >= RI_MIN_DETECTIONS; }
@@ -1163,6 +1162,7 @@ __global__ __launch_bounds__(256) void rt_append_kernel(RtArgs a, int first)
     const int ls = blockIdx.x, slot = first + ls;
     if (slot >= *a.rt_n) return;
     const int b = a.rt_lane[slot], t = threadIdx.x;
+    if (t == 0) a.cand_n[ls] = 0;                                             // the last reader of the list is done: clean for the next detection
     float *feat = a.feat + (int64_t)b * KS * 2;
     const int n_old = min(a.feat_n[b], KS);
     const int n_sel = min(a.sel_n[ls], 256);                                  // (ANMS returns at most 220; more would be dropped: flagged below)
@@ -1250,8 +1250,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
     // image-scale kernels chunk by chunk (the float64 integral images of `slots` detections are resident at once); the
     // candidate lists are per DETECTION, so the lane-serial bookkeeping runs once over all of them afterwards (round 2 ran it per
     // chunk: 1.4-2.7 ms of a near-idle GPU each time)
-    hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)B, st);
-    if (e != hipSuccess) return e;
+    // (the candidate counts are zero on entry: rt_append_kernel, the last kernel of this chain, clears what a detection used)
+    hipError_t e = hipSuccess;
     for (int first = 0; first < B; first += R) {
         const int P = min(R, B - first);
         const bool tr = trace && first == 0;
@@ -1293,9 +1293,9 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
         hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, 0);
     } else {
-        hipError_t e = hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);
+        hipError_t e = launch_det(st, a, 0, P);
         if (e != hipSuccess) return e;
-        return launch_det(st, a, 0, P);
+        return hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);   // (no bookkeeping follows that would clear the counts)
     }
     return hipGetLastError();
 }
