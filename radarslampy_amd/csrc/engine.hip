@@ -564,6 +564,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         r.SP = (e->W + 15) & ~15;
         ok = ok && dalloc(ctx, e, &r.S, (size_t)r.SP * e->W * R);
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.boxtab), retrack_boxtab_words(e->W));
+        ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.darktab), retrack_darktab_words(e->W));
         ok = ok && dalloc(ctx, e, &r.colT, (size_t)std::min(R, RT_TWO_PASS_SLOTS) * ((e->W + 63) / 64) * e->W);
         // candidate lists and bookkeeping tables per DETECTION (0.9 MB each): K4-K7 run once per step over all of them
         const size_t D = (size_t)B;
@@ -613,6 +614,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     e->tr_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_boxtab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.boxtab)));
+    if (e->rt_on) HIP_TRY(ctx, launch_retrack_darktab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.darktab)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
 }

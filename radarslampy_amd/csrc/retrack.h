@@ -16,6 +16,8 @@ struct RtArgs {
     const uint32_t *map;
     const uint32_t *boxtab;         // per (band, group, column wave) of the one-sweep integral kernel: the polar footprint of the patch,
                                     // {min ix | max ix << 16, min iy | max iy << 16} (max ix = 0xffff: nothing inside the maximum range)
+    const uint32_t *darktab;        // per column strip of the determinant kernel: which steps see nothing but pixels beyond the maximum range
+                                    // (retrack_darktab_words: 3 x 8 words per strip - step is dark / its load / its LDS fill can be skipped)
     float *feat;
     int32_t *feat_n;
     const double *vel;
@@ -55,3 +57,6 @@ hipError_t retrack_init();
 // fills boxtab (retrack_boxtab_words(W) uint32 words) from the sampling map: geometry only, once per engine
 size_t retrack_boxtab_words(int W);
 hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *boxtab);
+// fills darktab (retrack_darktab_words(W) zero-initialised uint32 words) from the sampling map: geometry only, once per engine
+size_t retrack_darktab_words(int W);
+hipError_t launch_retrack_darktab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *darktab);

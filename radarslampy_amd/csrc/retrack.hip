@@ -551,7 +551,8 @@ __device__ __forceinline__ void rt_push_maxima(const RtArgs &a, int ls, int r, i
 //     (sd_tile_fast); max(0, box) is the clamp modifier of the box's last subtraction (the ring holds the image scaled by 2^-10).
 //   * workgroup -> strip mapping is XCD-aware: the strips of a detection are consecutive workgroups of ONE XCD, started together
 //     and marching in step, so that the cache lines neighbouring strips share come from that XCD's L2 (hit rate 25 %).
-//   * a wave whose block of the image is (almost) empty - the corners beyond the maximum range - skips its step (see `dark`).
+//   * a step whose window lies beyond the maximum range - the corners of the image - skips its boxes, and the blocks only such steps
+//     would read are neither loaded nor staged (rt_darktab_kernel: a bit table per strip, geometry only).
 #define SD_T 16                             // position rows per step
 #define SD_RING 64
 #define SD_DUP 8
@@ -690,6 +691,48 @@ __device__ __forceinline__ double sd_dxy(double det, int r, int c, int H, int W,
     return __dsub_rn(det, __dmul_rn(0.81, __dmul_rn(dxy, dxy)));
 }
 
+// ---- which steps of a strip see nothing: geometry only, once per engine.
+// The Cartesian pixels beyond the maximum range (sampling-map word with ix >= cols: 21 % of the image, its four corners) are zero whatever
+// the scan holds.  A step whose whole window - position rows 16 t .. 16 t + 15 with their box rows -14 .. +16, the strip's position columns
+// with their box columns -14 .. +16 - lies there has box sums of exactly nothing (up to the rounding of the integral image's cumulative
+// sums, ~1e-9, against a threshold of 5e-4): its determinants can neither pass the threshold nor exceed a passing neighbour, they count as
+// 0.  Such a step skips the boxes; a 16-row block of the integral image that only such steps would read (steps j - 1, j, j + 1 for
+// block j) is not loaded.  The lit steps of a strip are ONE run (the range limit is a circle): the march starts just above it and stops
+// just below - the dark steps outside cost a barrier and a ring fill each, 40 % of a lit step.  Per strip SD_DT_WORDS words: [0, 8) bit
+// t = step t is dark, [8, 16) bit t = the block loaded AT step t (block t + 4) can be skipped, [16] / [17] = first / last lit step
+// (nt / -1: none).
+// (Round 3's first version tested the block's sum out of the ring in every wave and step - four LDS reads and a wait in front of every
+// step's boxes - and loaded every block.)
+#define SD_DT_WORDS 24
+__global__ __launch_bounds__(256) void rt_darktab_kernel(const uint32_t *__restrict__ map, int W, int cols, uint32_t *__restrict__ tab)
+{
+    const int H = W, strip = blockIdx.x, t = blockIdx.y, c0 = strip * SD_OUT;
+    const int ra = max(SD_T * t - SD_HL, 0), rb = min(SD_T * t + SD_T - 1 + SD_HR, H - 1);
+    const int xa = max(c0 - 1 - SD_HL, 0), xb = min(c0 - 1 + SD_PC - 1 + SD_HR, W - 1);
+    const int nx = xb - xa + 1, n = max(0, rb - ra + 1) * max(0, nx);
+    int lit = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = ra + i / nx, c = xa + i % nx;
+        if ((int)(map[(int64_t)r * W + c] & 4095u) < cols) lit = 1;
+    }
+    lit = __syncthreads_or(lit);
+    if (threadIdx.x == 0 && !lit) atomicOr(&tab[strip * SD_DT_WORDS + (t >> 5)], 1u << (t & 31));
+}
+__global__ __launch_bounds__(256) void rt_darkskip_kernel(int nt, uint32_t *__restrict__ tab)
+{
+    uint32_t *T = tab + blockIdx.x * SD_DT_WORDS;
+    const int t = threadIdx.x;
+    auto dark = [&](int q) { return q < 0 || q >= nt || ((T[q >> 5] >> (q & 31)) & 1u); };     // steps that do not exist read nothing
+    auto skip = [&](int j) { return dark(j - 1) && dark(j) && dark(j + 1); };
+    if (skip(t + 4)) atomicOr(&T[8 + (t >> 5)], 1u << (t & 31));
+    if (t == 0) {
+        int first = nt, last = -1;
+        for (int q = 0; q < nt; q++)
+            if (!dark(q)) { if (first == nt) first = q; last = q; }
+        T[16] = (uint32_t)first; T[17] = (uint32_t)last;
+    }
+}
+
 template <int P> struct SdTag { static constexpr int value = P; };
 
 __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int first, int P, int nstrips)
@@ -703,7 +746,9 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
     const int ls = work / nstrips, strip = work - ls * nstrips;
     const int W = a.W, H = a.W, SP = a.SP;
     const double thr = a.threshold;
-    const double dark_sum = 225.0 * sqrt(thr) * 0.5 * 0.95 * SD_SCALE;       // (5 % under the bound: the sums are rounded; ring units)
+    typedef const uint32_t __attribute__((address_space(4))) *SdConstPtr;     // constant address space + uniform address = scalar load
+    const SdConstPtr dtab = (SdConstPtr)(uintptr_t)(a.darktab + strip * SD_DT_WORDS);
+    uint32_t dk_w = 0, skf_w = 0;                                           // the words of the current 32 steps: dark / skip the load
     const double *__restrict__ S = a.S + (int64_t)ls * SP * W;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), w8 = wave & 7, half = wave >> 3;   // half < SD_HALVES
@@ -743,10 +788,25 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
         loff[j] = (uint32_t)(srow[j] * SD_PITCHB + scol[j] * 8);
     }
     double stage[2][SD_NST];
-    int frow = 0;                                                          // first image row of the next load: 16 t + 16, t = -1, 0, ..
-    auto fetch = [&](double(&st)[SD_NST]) {
-        const char *base = reinterpret_cast<const char *>(S + (int64_t)frow * SP + cbase);     // (wave-uniform)
-        if (frow >= 0 && frow + SD_T <= H && strip_inside) {
+    const int nt = H / SD_T + 1;                                           // the last step's last row lies outside the image
+    // the march covers the strip's lit steps [first, last] only: it starts on the multiple of four at or below first - 1 (a dark step, or
+    // step 0: nothing above it is read; the per-position maxima of "the step before" start as zeros, which is what dark steps hold) and
+    // ends with step last + 1, whose zeros close the maxima of step last
+#ifdef SD_NO_TRIM
+    const int t_first = 0, t_last = nt - 1;
+#else
+    const int t_first = (int)dtab[16], t_last = (int)dtab[17];
+#endif
+    if (t_first >= nt) return;                                             // nothing but the corners: no candidates (uniform: before any barrier)
+    const int tb = t_first >= 1 ? ((t_first - 1) & ~3) : 0, te = min(nt, t_last + 2);
+    int frow = SD_T * tb;                                                  // first image row of the next load: 16 t + 16, t = tb - 1, tb, ..
+    // (skip: only dark steps would read the block - its loads are pointed at the strip's first block instead, lines this workgroup has
+    // in its L1 since the prologue: the same instructions on both paths keep the compiler's vmcnt bookkeeping exact, a branch around
+    // the loads made every later wait a wait for ALL outstanding loads and cost more than the traffic it saved)
+    auto fetch = [&](double(&st)[SD_NST], bool skip = false) {
+        const bool whole = frow >= 0 && frow + SD_T <= H && strip_inside;
+        const char *base = reinterpret_cast<const char *>(S + (int64_t)((skip && whole) ? 0 : frow) * SP + cbase);       // (wave-uniform)
+        if (whole) {
 #pragma unroll
             for (int j = 0; j < SD_NST; j++)
                 if (SD_THREADS * (j + 1) <= SD_T * SD_BP || tid + SD_THREADS * j < SD_T * SD_BP) st[j] = *reinterpret_cast<const double *>(base + goff[j]);
@@ -799,7 +859,6 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
             }
         }
     };
-    const int nt = H / SD_T + 1;                                           // the last step's last row lies outside the image
     // prologue: per-position maxima cleared (rows above the image count as zero), rows 0..31 of the image, loads of steps 1 and 2 in flight
     for (int i = tid; i < 2 * SD_M2_ROWS * SD_PC; i += SD_THREADS) reinterpret_cast<double *>(sd_smem + SD_RING_BYTES)[i] = 0.0;
     fetch(stage[1]);
@@ -811,25 +870,15 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
     __syncthreads();
     auto step = [&](auto tag, int t) {
         constexpr int PH = decltype(tag)::value, WB = PH & 1;
-        // rows of step t + 1 (loaded two steps ago) into slots that step t does not read; then the loads of step t + 3
+        // rows of step t + 1 (loaded two steps ago) into slots that step t does not read; then the loads of step t + 3 - unless only
+        // dark steps would read them (rt_darktab_kernel)
+        const uint32_t tb = 1u << (t & 31);
         put((PH + 2) & 3, stage[(PH + 1) & 1]);
-        fetch(stage[(PH + 1) & 1]);
+        fetch(stage[(PH + 1) & 1], (skf_w & tb) != 0);
         if (t >= 1) maxima(t - 1, WB ^ 1);
         const int rbase = SD_T * t;
         const bool fast = t >= 1 && rbase + SD_T - 1 + SD_HR <= H - 1;
-        // A wave whose positions see (almost) nothing skips the step: every box of every one of its positions lies inside the block
-        // rows (rbase + w8 - 14, rbase + w8 + 8 (SD_T / 8 - 1) + 16] x columns (first - 14, last + 16], boxes are >= 0, and with the block's
-        // sum T: |dxx| = |2 side - rest| / 225 <= 2 T / 225, likewise dyy, so dxx * dyy <= 4 T^2 / 225^2 <= threshold for
-        // T <= 225 sqrt(0.0005) / 2 = 2.51 (size 30: 10.06).  Such products can neither pass nor exceed a passing neighbour - they
-        // count as 0.  (The corners of the Cartesian image beyond the maximum range, 21 % of it, are exactly zero.)
-        bool dark = false;
-        if (wave_live) {
-            const int ra = max(rbase + w8 - SD_HL, 0), rb = min(rbase + w8 + 8 * (SD_T / 8 - 1) + SD_HR, H - 1);
-            const int xa = clipi(c0 - 1 + half * 64 - SD_HL, 0, W - 1), xb = clipi(c0 - 1 + half * 64 + 63 + SD_HR, 0, W - 1);
-            auto at = [&](int rr, int cc) { return *reinterpret_cast<const double *>(sd_smem + (((rr & (SD_RING - 1)) * SD_BP + (cc - cbase)) * 8)); };
-            const double tsum = __dsub_rn(__dsub_rn(__dadd_rn(at(ra, xa), at(rb, xb)), at(ra, xb)), at(rb, xa));
-            dark = __builtin_amdgcn_readfirstlane(tsum <= dark_sum ? 1 : 0) != 0;
-        }
+        const bool dark = (dk_w & tb) != 0;                                 // every box of every position of this step lies beyond the maximum range
         if (!wave_live || dark) {
 #pragma unroll
             for (int k = 0; k < SD_T / 8; k++) { d0[k] = 0.0; d1[k] = 0.0; }
@@ -862,13 +911,20 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
         }
         __syncthreads();
     };
-    for (int t = 0; t < nt; t += 4) {
+    for (int t = tb; t < te; t += 4) {
+        if ((t & 31) == 0 || t == tb) { dk_w = dtab[t >> 5]; skf_w = dtab[8 + (t >> 5)]; }
+#ifdef SD_NO_LOADSKIP
+        skf_w = 0;
+#endif
+#ifdef SD_NO_DARK
+        dk_w = 0;
+#endif
         step(SdTag<0>(), t);
-        if (t + 1 < nt) step(SdTag<1>(), t + 1);
-        if (t + 2 < nt) step(SdTag<2>(), t + 2);
-        if (t + 3 < nt) step(SdTag<3>(), t + 3);
+        if (t + 1 < te) step(SdTag<1>(), t + 1);
+        if (t + 2 < te) step(SdTag<2>(), t + 2);
+        if (t + 3 < te) step(SdTag<3>(), t + 3);
     }
-    maxima(nt - 1, (nt - 1) & 1);
+    maxima(te - 1, (te - 1) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------ K4: ordered candidates
@@ -1224,6 +1280,17 @@ hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int
 {
     if (W > 2048) return hipSuccess;                                       // (the one-sweep kernel is not used for such images)
     hipLaunchKernelGGL(rt_boxtab_kernel, dim3((unsigned)(retrack_boxtab_words(W) / 2)), dim3(64), 0, st, map, W, cols, boxtab);
+    return hipGetLastError();
+}
+
+size_t retrack_darktab_words(int W) { return (size_t)((W + SD_OUT - 1) / SD_OUT) * SD_DT_WORDS; }
+
+hipError_t launch_retrack_darktab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *darktab)
+{
+    const int ns = (W + SD_OUT - 1) / SD_OUT, nt = W / SD_T + 1;
+    if (nt > 256) return hipSuccess;                                         // (images above 4080 rows: nothing is skipped)
+    hipLaunchKernelGGL(rt_darktab_kernel, dim3(ns, nt), dim3(256), 0, st, map, W, cols, darktab);
+    hipLaunchKernelGGL(rt_darkskip_kernel, dim3(ns), dim3(256), 0, st, nt, darktab);
     return hipGetLastError();
 }
 
