@@ -435,11 +435,24 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
     live = None
     if not args.dry_engine:
         knames = ["ingest_peaks", "warp_quantise", "pyramid"] + ([] if args.no_retrack else ["doh_integral", "doh_det_maxima"])
-        live = {k: eng.kernel_avg(k, args.steps)[0] for k in knames}
+        live = {k: eng.kernel_avg(k, args.steps)[0] for k in knames[:3]}
         if not args.no_retrack:
+            # detection kernels: EVERY busy chunk launch of the timed steps.  A step launches ceil(lanes / retrack_slots) chunks whatever
+            # the number n of lanes that re-detect (only the device knows it); chunk c holds clamp(n - c * slots, 0, slots) detections,
+            # and n is in the result records consumed above.  live[k] = mean duration of the busy launches, their detections on average
+            # = doh_units_per_launch (the first chunk of a step overlaps the front end of later steps, the others mostly run alone)
             slots_ = min(B // len(engs), args.retrack_slots or 512)
-            per = [min(slots_, stat.get("per_step", {}).get(pre + args.warmup + k, 0)) for k in range(args.steps)]
-            live["doh_units_per_launch"] = float(np.mean(per)) if per else 0.0      # detections in the first chunk of a step, on average
+            nst = min(args.steps, 64)
+            n_step = [stat.get("per_step", {}).get(pre + args.warmup + k, 0) for k in range(args.steps - nst, args.steps)]
+            for k in knames[3:]:
+                m = eng.kernel_chunk_ms(k, nst)
+                tot, nb = 0.0, 0
+                for srow, n_ in zip(m[-len(n_step):], n_step[-len(m):]):
+                    busy = min(len(srow), -(-n_ // slots_))
+                    tot += float(srow[:busy].sum()); nb += busy
+                live[k] = tot / nb if nb else 0.0
+                live["doh_busy_launches"] = nb
+            live["doh_units_per_launch"] = float(sum(n_step)) / live["doh_busy_launches"] if live.get("doh_busy_launches") else 0.0
     if comm is not None:
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
 
@@ -586,16 +599,16 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     """roofline of the dominant HBM-streaming kernel of a step.  Candidates: the three front-end kernels (once per lane and
     step) and the two image-scale kernels of the feature re-detection (once per RETRACKING lane: weighted by the observed
     retrack fraction).  `avg_launch_ms` is the kernel's average launch duration over the K timed steps from HIP event pairs the
-    engine records on the stream the kernel runs on (roam_engine_kernel_avg, read right after the timed region; nothing
-    synchronises inside it) - for a detection kernel the first chunk of every step, whose algorithmic bytes are those of the
-    detections it really held (`units_per_launch`, from the per-step result records).  In the pipelined engine other kernels
+    engine records on the stream the kernel runs on (roam_engine_kernel_avg / roam_engine_kernel_chunk_ms, read right after the timed
+    region; nothing synchronises inside it) - for a detection kernel every busy chunk launch of those steps, whose algorithmic bytes
+    are those of the detections they really held (`units_per_launch`, from the per-step result records).  In the pipelined engine other kernels
     share the GPU during those launches, so every candidate is also re-launched alone after the timed region
     (roam_engine_time_kernel, HIP events on its stream) = `isolated_*`.
     `traffic` = memory-side bytes per launch from the committed PMC passes of that kernel, gfx950-corrected as the microarchitecture
     guide prescribes (FETCH_SIZE tallies 128-byte requests at 64 bytes: x 2; cross-checked with TCC_MISS x 128 B), scaled to the
     detections per launch; null when the kernel's source changed after the passes were taken."""
     names = ["ingest_peaks", "warp_quantise", "pyramid"]
-    live = {k: v for k, v in live_all.items() if k != "doh_units_per_launch"}
+    live = {k: v for k, v in live_all.items() if k not in ("doh_units_per_launch", "doh_busy_launches")}
     iso = {k: eng.time_kernel(k, args.kernel_reps) for k in names}
     per_step = {k: iso[k][0] for k in names}                       # ms of the kernel alone per step
     slots = None
@@ -608,9 +621,9 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     dom = max(per_step, key=per_step.get)
     algo_bytes = iso[dom][1]
     units = slots if dom.startswith("doh") else B
-    # in-step duration over the K timed steps.  Front-end kernels: one launch per step over all lanes.  Detection kernels: the
-    # first chunk of every step, which holds min(retrack_slots, lanes that re-detected in that step) detections - the algorithmic
-    # bytes of the live figure are those of the average number of detections per such launch
+    # in-step duration over the K timed steps.  Front-end kernels: one launch per step over all lanes.  Detection kernels: every
+    # busy chunk launch of those steps - the algorithmic bytes of the live figure are those of the average number of detections per
+    # such launch
     ms = live.get(dom, iso[dom][0])
     if dom.startswith("doh") and live_all.get("doh_units_per_launch", 0) > 0 and ms > 0:
         units = live_all["doh_units_per_launch"]

@@ -279,6 +279,13 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
  * min(retrack_slots, lanes that re-detected in the step) detections; n_used counts the steps that had device-side
  * detection switched on */
 int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_steps, float *avg_ms, int32_t *n_used);
+/* "doh_integral" | "doh_det_maxima", chunk by chunk: ms_out[s * *chunks + c] = launch duration of chunk c in the s-th of the last
+ * *steps_out (<= last_steps, <= 64) steps, oldest first; -1 for a step without device-side detection.  A step launches
+ * ceil(lanes / retrack_slots) chunks (the first 16 are traced) whatever the number n of lanes that re-detect - only the device
+ * knows it; chunk c holds clamp(n - c * retrack_slots, 0, retrack_slots) detections, n is in the step's result records.
+ * cap (floats) >= last_steps * 16 always suffices */
+int32_t roam_engine_kernel_chunk_ms(roam_ctx *ctx, const char *name, int32_t last_steps, float *ms_out, int32_t cap, int32_t *chunks,
+                                    int32_t *steps_out);
 /* time `reps` launches of the dominant streaming kernel (warp+quantise of all lanes) with
  * HIP events on the context stream; returns average ms per launch. */
 int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms,

@@ -98,7 +98,7 @@ struct Engine {
     // kept for the last TRACE_RING steps so that a caller can average a kernel's launch time over a timed
     // region without synchronising inside it (roam_engine_kernel_avg)
     hipEvent_t tr_ev[64][6] = {};
-    hipEvent_t rt_ev[64][3] = {};                                      // first detection chunk of a step: integral image | determinants
+    hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
     bool tr_ok = false;
     bool ev_ok = false, stepped = false, uploads_pending = false;
@@ -1079,7 +1079,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
         e->rt.res = res_slot;
         HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->rt_ev[e->nstep & 63]));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->rt_ev[e->nstep & 63], RT_TRACE_CHUNKS));
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }
     e->rt_ev_ok[e->nstep & 63] = e->rt_on && e->rt_mode;
@@ -1221,7 +1221,7 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
     ARG_CHECK(ctx, name && last_steps >= 1 && avg_ms && n_used);
     int k = !strcmp(name, "ingest_peaks") ? 0 : (!strcmp(name, "warp_quantise") ? 1 : (!strcmp(name, "pyramid") ? 2 : -1));
     // the two image-scale kernels of the detection: the FIRST chunk of every step (min(retrack_slots, lanes flagged in that step)
-    // detections; steps without device-side detection do not count)
+    // detections; steps without device-side detection do not count) - roam_engine_kernel_chunk_ms has every chunk
     const int kd = !strcmp(name, "doh_integral") ? 0 : (!strcmp(name, "doh_det_maxima") ? 1 : -1);
     if (k < 0 && kd < 0) { ROAM_SET_ERR(ctx, "unknown kernel '%s'", name); return ROAM_E_ARG; }
     if (kd >= 0 && !e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
@@ -1249,6 +1249,34 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
     }
     *avg_ms = (float)(sum / (double)n);
     *n_used = (int32_t)n;
+    return ROAM_OK;
+}
+
+// launch durations of a detection kernel, chunk by chunk: ms_out[s * chunks + c] = chunk c of the s-th of the last `steps_out`
+// steps (oldest first; -1 for a step without device-side detection).  A step launches `chunks` = ceil(lanes / retrack_slots) chunks
+// (at most RT_TRACE_CHUNKS are traced) whatever the number of lanes that re-detect - only the device knows it - and chunk c holds
+// clamp(n - c * retrack_slots, 0, retrack_slots) of the step's n detections: the caller has n in the step's result records
+int32_t roam_engine_kernel_chunk_ms(roam_ctx *ctx, const char *name, int32_t last_steps, float *ms_out, int32_t cap, int32_t *chunks,
+                                    int32_t *steps_out)
+{
+    ENGINE();
+    ARG_CHECK(ctx, name && last_steps >= 1 && ms_out && chunks && steps_out);
+    const int kd = !strcmp(name, "doh_integral") ? 0 : (!strcmp(name, "doh_det_maxima") ? 1 : -1);
+    if (kd < 0) { ROAM_SET_ERR(ctx, "unknown kernel '%s'", name); return ROAM_E_ARG; }
+    if (!e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
+    if (!e->stepped) { ROAM_SET_ERR(ctx, "run a step first"); return ROAM_E_STATE; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n = std::min<int64_t>(std::min<int64_t>(last_steps, e->nstep), 64);
+    const int nchunk = std::min((e->B + e->rt.slots - 1) / e->rt.slots, RT_TRACE_CHUNKS);
+    ARG_CHECK(ctx, (int64_t)cap >= n * nchunk);
+    for (int64_t i = e->nstep - n, s = 0; i < e->nstep; i++, s++)
+        for (int c = 0; c < nchunk; c++) {
+            float ms = -1.f;
+            if (e->rt_ev_ok[i & 63]) HIP_TRY(ctx, hipEventElapsedTime(&ms, e->rt_ev[i & 63][3 * c + kd], e->rt_ev[i & 63][3 * c + kd + 1]));
+            ms_out[s * nchunk + c] = ms;
+        }
+    *chunks = nchunk;
+    *steps_out = (int32_t)n;
     return ROAM_OK;
 }
 

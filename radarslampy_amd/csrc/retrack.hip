@@ -1311,7 +1311,7 @@ static hipError_t launch_det(hipStream_t st, const RtArgs &a, int first, int P)
     return hipGetLastError();
 }
 
-hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace)
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace)
 {
     const int W = a.W, R = a.slots;
     // image-scale kernels chunk by chunk (the float64 integral images of `slots` detections are resident at once); the
@@ -1321,17 +1321,18 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
     hipError_t e = hipSuccess;
     for (int first = 0; first < B; first += R) {
         const int P = min(R, B - first);
-        const bool tr = trace && first == 0;
-        if (tr && (e = hipEventRecord(trace[0], st)) != hipSuccess) return e;
+        const bool tr = trace && first / R < ntrace;
+        hipEvent_t *tev = trace + 3 * (first / R);
+        if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, first);
-        if (tr && (e = hipEventRecord(trace[1], st)) != hipSuccess) return e;
+        if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
         if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
-        if (tr && (e = hipEventRecord(trace[2], st)) != hipSuccess) return e;
+        if (tr && (e = hipEventRecord(tev[2], st)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
     hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, a, 0);

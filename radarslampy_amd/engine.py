@@ -223,6 +223,15 @@ class Engine:
         self.ctx.check(self.lib.roam_engine_kernel_avg(self.ctx.h, name.encode(), int(last_steps), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def kernel_chunk_ms(self, name: str, last_steps: int):
+        """(steps, chunks) float32 array: launch duration in ms of every detection chunk of the last steps, oldest first
+        (-1: the step ran without device-side detection) - roam_engine_kernel_chunk_ms"""
+        buf = np.zeros(int(last_steps) * 16, dtype=np.float32)
+        nc, ns = C.c_int32(0), C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_kernel_chunk_ms(self.ctx.h, name.encode(), int(last_steps), buf.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            buf.size, C.byref(nc), C.byref(ns)))
+        return buf[: ns.value * nc.value].reshape(ns.value, nc.value)
+
     def time_kernel(self, name: str, reps: int = 20):
         ms = C.c_float(0)
         by = C.c_double(0)

@@ -120,6 +120,9 @@ def test_large_chunk_takes_the_one_sweep_integral_kernel():
         for name in ("doh_integral", "doh_det_maxima"):          # live event pairs around the first detection chunk of the step
             ms, n = eng.kernel_avg(name, 1)
             assert n == 1 and 0.0 < ms < 1000.0, (name, ms, n)
+            m = eng.kernel_chunk_ms(name, 1)                     # ... and around every chunk: lanes / slots of them, all busy here
+            assert m.shape == (1, -(-lanes // slots)) and (m > 0.0).all() and (m < 1000.0).all(), (name, m)
+            assert abs(float(m[0, 0]) - ms) < 1e-6
         for b in range(lanes):
             w, blobs = want[b % 3]
             assert res[b]["retracked_on_device"] and res[b]["detect_overflow"] == 0, (slots, b)
