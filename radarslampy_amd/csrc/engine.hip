@@ -101,6 +101,8 @@ struct Engine {
     hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
     bool tr_ok = false;
+    static constexpr bool warp_dark_zero = true;   // the pyramids are zero-filled at creation and level 0 is written by the warp only:
+                                                    // its tiles beyond the maximum range are never stored (0.6 ms of 11.4 per 4096 scans)
     bool ev_ok = false, stepped = false, uploads_pending = false;
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
     // device-side retracks (mode 1) grow a lane to at most 60 + 256 features without the host knowing which lane; a step in
@@ -800,7 +802,7 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
     // previous-image pyramid of this lane from the pool scan
     uint8_t *pyr = e->pyr[e->cur] + (size_t)lane * e->pd.lane_stride;
     WarpSrc ws = {e->pool + (size_t)pool_idx * e->rec_bytes, 0, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, nullptr};
-    HIP_TRY(ctx, launch_warp_gather(ctx->stream, e->warp_map, ws, 1, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride));
+    HIP_TRY(ctx, launch_warp_gather(ctx->stream, e->warp_map, ws, 1, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride, e->warp_dark_zero));
     HIP_TRY(ctx, launch_build_pyramid(ctx->stream, pyr, e->pd, 1));
     double zero[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane, pose3, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
@@ -949,7 +951,7 @@ int32_t roam_engine_init_lanes_detect(roam_ctx *ctx, int32_t lane0, int32_t n, c
     HIP_TRY(ctx, hipMemcpyAsync(e->rt.rt_scan, pool_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
     // previous-image pyramids from the pool scans (lane i of the launch reads record rt_scan[i])
     uint8_t *pyr = e->pyr[e->cur] + (size_t)lane0 * e->pd.lane_stride;
-    HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->rt.rt_scan), n, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride));
+    HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->rt.rt_scan), n, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride, e->warp_dark_zero));
     HIP_TRY(ctx, launch_build_pyramid(st, pyr, e->pd, n));
     // pose, zero velocity, empty feature set, keyframe at the pose created on the scan (set_features_impl with K = 0)
     HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane0, poses3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1021,7 +1023,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipEventRecord(tr[5], sP));
     HIP_TRY(ctx, hipEventRecord(e->ev_peaks, sP));
     HIP_TRY(ctx, hipEventRecord(tr[1], sA));
-    HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride));
+    HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride, e->warp_dark_zero));
     HIP_TRY(ctx, hipEventRecord(tr[2], sA));
     HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
     HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
@@ -1300,7 +1302,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     HIP_TRY(ctx, hipEventRecord(a, st));
     for (int r = 0; r < reps; r++) {
         if (!strcmp(name, "warp_quantise")) {
-            HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx[e->pk]), B, c.rows, c.clip, next, e->pd.lane_stride));
+            HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->scan_idx[e->pk]), B, c.rows, c.clip, next, e->pd.lane_stride, e->warp_dark_zero));
             bytes = (double)B * ((double)c.rows * c.clip + (double)e->W * e->W);
         } else if (!strcmp(name, "ingest_peaks")) {
             PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[e->pk]};

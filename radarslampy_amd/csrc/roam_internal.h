@@ -93,8 +93,10 @@ hipError_t launch_polar_to_cart(hipStream_t st, WarpSrc src, int B, int rows, in
                                 int64_t f32_lane_stride);
 // engine path: precomputed sampling map (W x W u32) + gather
 hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map);
+// dark_stays_zero: the tiles beyond the maximum range (a fifth of the image, zero whatever the scan holds) are not written - for
+// destinations that were zero-filled once and are written by this kernel only (the engine's pyramids)
 hipError_t launch_warp_gather(hipStream_t st, const uint32_t *map, WarpSrc src, int B, int rows, int cols,
-                              uint8_t *cart_u8, int64_t u8_lane_stride);
+                              uint8_t *cart_u8, int64_t u8_lane_stride, bool dark_stays_zero = false);
 hipError_t launch_quantize_u8(hipStream_t st, const float *img, int64_t n, uint8_t *out);
 
 // pyramid storage: level l of lane b at base + b*lane_stride + level_off[l]

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
                                                           int64_t lane_stride, int64_t row_stride, int payload_off,
                                                           const int32_t *__restrict__ lane_index, int B, int rows,
                                                           int cols, int W, uint8_t *__restrict__ cart_u8,
-                                                          int64_t u8_lane_stride, int gx, int gy, int total)
+                                                          int64_t u8_lane_stride, int gx, int gy, int total, int dark_stays_zero)
 {
     __shared__ __align__(16) float box[WG_BOX_ELEMS];
     __shared__ int red[4][4];
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     const bool sok = sy < W && sx + 3 < W;
     const uint32_t psel = 0x0c0c0000u | (uint32_t)qi | ((uint32_t)(4 + qi) << 8);
     uint8_t *dst = cart_u8 + (int64_t)sy * W + sx;
-    if (!any) {                                       // beyond the maximum range: zeros
-        if (sok)
+    if (!any) {                                       // beyond the maximum range: zeros (dark_stays_zero: the destination was
+        if (sok && !dark_stays_zero)                  // zero-filled once and only this kernel writes it - nothing to do)
             for (int l = l0; l < l1; l++) *reinterpret_cast<uint32_t *>(dst + (int64_t)l * u8_lane_stride) = 0u;
         return;
     }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
 
 // requires W % 4 == 0, u8_lane_stride % 4 == 0, rows * row_stride + cols < 2^31
 hipError_t launch_warp_gather(hipStream_t st, const uint32_t *map, WarpSrc src, int B, int rows, int cols,
-                              uint8_t *cart_u8, int64_t u8_lane_stride)
+                              uint8_t *cart_u8, int64_t u8_lane_stride, bool dark_stays_zero)
 {
     const int R = cols / 2, W = 2 * R;
     const int gx = (W + WG_TW - 1) / WG_TW, gy = (W + WG_TH - 1) / WG_TH, gz = (B + WG_LB - 1) / WG_LB;
@@ -421,7 +421,7 @@ hipError_t launch_warp_gather(hipStream_t st, const uint32_t *map, WarpSrc src, 
     const unsigned blocks = (unsigned)(((total + 7) >> 3) << 3);
     hipLaunchKernelGGL(warp_gather_kernel, dim3(blocks), dim3(256), 0, st, map, reinterpret_cast<const uint8_t *>(src.base),
                        src.lane_stride, src.row_stride, src.payload_off, src.lane_index, B, rows, cols, W, cart_u8,
-                       u8_lane_stride, gx, gy, (int)total);
+                       u8_lane_stride, gx, gy, (int)total, dark_stays_zero ? 1 : 0);
     return hipGetLastError();
 }
 
