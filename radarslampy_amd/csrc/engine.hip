@@ -101,6 +101,7 @@ struct Engine {
     hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
     bool tr_ok = false;
+    unsigned long long *pyr_dark = nullptr;        // lanes of the 2024 -> 1012 pyramid kernel that see nothing but pixels beyond the maximum range
     static constexpr bool warp_dark_zero = true;   // the pyramids are zero-filled at creation and level 0 is written by the warp only:
                                                     // its tiles beyond the maximum range are never stored (0.6 ms of 11.4 per 4096 scans)
     bool ev_ok = false, stepped = false, uploads_pending = false;
@@ -499,6 +500,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->pyr[1], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[2], (size_t)e->pd.lane_stride * B);
     ok = ok && dalloc(ctx, e, &e->pyr[3], (size_t)e->pd.lane_stride * B);
+    ok = ok && dalloc(ctx, e, &e->pyr_dark, pyr_dark_words(e->W));
     ok = ok && dalloc(ctx, e, &e->warp_map, (size_t)e->W * e->W);
     ok = ok && dalloc(ctx, e, &e->row_stage, (size_t)B * cfg->rows * e->stage_cap);
     ok = ok && dalloc(ctx, e, &e->row_count, (size_t)B * cfg->rows);
@@ -615,6 +617,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
                 if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     e->tr_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
+    HIP_TRY(ctx, launch_pyr_dark(ctx->stream, e->warp_map, e->W, e->W, cfg->clip, e->pyr_dark));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_boxtab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.boxtab)));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_darktab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.darktab)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -803,7 +806,7 @@ int32_t roam_engine_init_lane(roam_ctx *ctx, int32_t lane, int32_t pool_idx, con
     uint8_t *pyr = e->pyr[e->cur] + (size_t)lane * e->pd.lane_stride;
     WarpSrc ws = {e->pool + (size_t)pool_idx * e->rec_bytes, 0, (int64_t)e->cfg.stride, e->cfg.payload_off, 1, nullptr};
     HIP_TRY(ctx, launch_warp_gather(ctx->stream, e->warp_map, ws, 1, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride, e->warp_dark_zero));
-    HIP_TRY(ctx, launch_build_pyramid(ctx->stream, pyr, e->pd, 1));
+    HIP_TRY(ctx, launch_build_pyramid(ctx->stream, pyr, e->pd, 1, e->pyr_dark));
     double zero[3] = {0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane, pose3, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(e->vel + 3 * (size_t)lane, zero, sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
@@ -952,7 +955,7 @@ int32_t roam_engine_init_lanes_detect(roam_ctx *ctx, int32_t lane0, int32_t n, c
     // previous-image pyramids from the pool scans (lane i of the launch reads record rt_scan[i])
     uint8_t *pyr = e->pyr[e->cur] + (size_t)lane0 * e->pd.lane_stride;
     HIP_TRY(ctx, launch_warp_gather(st, e->warp_map, pool_warp_src(e, e->rt.rt_scan), n, e->cfg.rows, e->cfg.clip, pyr, e->pd.lane_stride, e->warp_dark_zero));
-    HIP_TRY(ctx, launch_build_pyramid(st, pyr, e->pd, n));
+    HIP_TRY(ctx, launch_build_pyramid(st, pyr, e->pd, n, e->pyr_dark));
     // pose, zero velocity, empty feature set, keyframe at the pose created on the scan (set_features_impl with K = 0)
     HIP_TRY(ctx, hipMemcpyAsync(e->pose + 3 * (size_t)lane0, poses3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(e->kf_pose + 3 * (size_t)lane0, poses3, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1028,7 +1031,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
     HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
     HIP_TRY(ctx, hipEventRecord(tr[3], sB));
-    HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B));
+    HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B, e->pyr_dark));
     HIP_TRY(ctx, hipEventRecord(tr[4], sB));
     HIP_TRY(ctx, hipEventRecord(e->ev_join, sB));                         // end of stage B
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
@@ -1328,7 +1331,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             // image written once; determinants + maxima = float64 image read once (the candidates it writes are a few KB)
             bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 4.0 + npx * 8.0) : npx * 8.0);
         } else if (!strcmp(name, "pyramid")) {
-            HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B));
+            HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B, e->pyr_dark));
             double rd = 0, wr = 0;
             for (int l = 0; l + 1 < ROAM_PYR_LEVELS; l++) { rd += (double)e->pd.w[l] * e->pd.h[l]; wr += (double)e->pd.w[l + 1] * e->pd.h[l + 1]; }
             bytes = (double)B * (rd + wr);

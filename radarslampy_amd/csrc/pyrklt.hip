@@ -221,9 +221,11 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 struct PwRow { uint32_t d[PW_DPL]; };
 
-__device__ __forceinline__ void pw_load(const uint8_t *__restrict__ s, int w, int h, int wq, int sy, int b0, PwRow &r)
+// dk: this lane's pixels are zero for every row of the band (pyr_dark_kernel) - its loads are pointed at the first bytes of the image,
+// which lie beyond the maximum range too: zeros out of the cache instead of zeros out of HBM, with the same instructions on both paths
+__device__ __forceinline__ void pw_load(const uint8_t *__restrict__ s, int w, int h, int wq, int sy, int b0, PwRow &r, bool dk = false)
 {
-    const uint32_t *rp = reinterpret_cast<const uint32_t *>(s + (int64_t)sy * w) + b0;
+    const uint32_t *rp = dk ? reinterpret_cast<const uint32_t *>(s) : reinterpret_cast<const uint32_t *>(s + (int64_t)sy * w) + b0;
     if (sy < h - 1) {                                    // reading past the row end stays inside the image
         const u32x4_a4 a = *reinterpret_cast<const u32x4_a4 *>(rp), c = *reinterpret_cast<const u32x4_a4 *>(rp + 4);
         r.d[0] = a.x; r.d[1] = a.y; r.d[2] = a.z; r.d[3] = a.w; r.d[4] = c.x; r.d[5] = c.y; r.d[6] = c.z; r.d[7] = c.w;
@@ -249,9 +251,42 @@ __device__ __forceinline__ void pw_hfilter(const PwRow &r, int lane, int jstar, 
     for (int j = 0; j < PW_DPL; j++) out[j] = pyr_hpair(D[j], D[1 + j], D[2 + j]);
 }
 
+// which lanes of pyr_down_wave_kernel see nothing in a band: every pixel of the lane's 32-pixel segment (with its filter taps) in the
+// band's input rows lies beyond the maximum range of the sampling map - geometry only, once per engine.  Bit l of dark[band].
+__global__ __launch_bounds__(64) void pyr_dark_kernel(const uint32_t *__restrict__ map, int w, int h, int cols, int dh, unsigned long long *__restrict__ dark)
+{
+    const int band = blockIdx.x, lane = threadIdx.x, oy0 = band * PW_CH, nout = min(PW_CH, dh - oy0);
+    const int r0 = max(0, 2 * oy0 - 2), r1 = min(h - 1, 2 * oy0 + 2 * nout + 1);
+    const int c0 = max(0, 32 * lane - 4), c1 = min(w - 1, 32 * lane + 35);
+    bool dk = c0 <= c1;
+    for (int r = r0; r <= r1 && dk; r++)
+        for (int c = c0; c <= c1; c++)
+            if ((int)(map[(int64_t)r * w + c] & 4095u) < cols) { dk = false; break; }
+    const unsigned long long m = __ballot(dk);
+    if (lane == 0) dark[band] = m;
+}
+
+size_t pyr_dark_words(int h) { return (size_t)(((h + 1) / 2 + PW_CH - 1) / PW_CH); }
+
+// fills dark (pyr_dark_words(h) 64-bit words) for a w x h level-0 image sampled through `map`; the table is only valid - and only then
+// left non-zero - when the image's first 32 bytes are themselves beyond the maximum range (the dummy source of the dark lanes)
+hipError_t launch_pyr_dark(hipStream_t st, const uint32_t *map, int w, int h, int cols, unsigned long long *dark)
+{
+    const int dh = (h + 1) / 2, bands = (dh + PW_CH - 1) / PW_CH;
+    hipLaunchKernelGGL(pyr_dark_kernel, dim3(bands), dim3(64), 0, st, map, w, h, cols, dh, dark);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    unsigned long long first = 0;
+    if ((e = hipMemcpyAsync(&first, dark, sizeof(first), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if (!(first & 1ull)) return hipMemsetAsync(dark, 0, sizeof(unsigned long long) * bands, st);
+    return hipSuccess;
+}
+
 __global__ __launch_bounds__(256) void pyr_down_wave_kernel(const uint8_t *__restrict__ src, int64_t src_lane_stride,
                                                             int w, int h, uint8_t *__restrict__ dst,
-                                                            int64_t dst_lane_stride, int dw, int dh, int bands)
+                                                            int64_t dst_lane_stride, int dw, int dh, int bands,
+                                                            const unsigned long long *__restrict__ dark)
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -268,14 +303,16 @@ __global__ __launch_bounds__(256) void pyr_down_wave_kernel(const uint8_t *__res
     const int jstar = wq - 1 - b0;                       // local index of the last pixel dword of the row (if in this lane)
     uint32_t R[5][PW_DPL];
     PwRow pre[2];
-    pw_load(s, w, h, wq, reflect101(2 * oy0 - 2, h), b0, pre[0]);
-    if (nin > 1) pw_load(s, w, h, wq, reflect101(2 * oy0 - 1, h), b0, pre[1]);
+    // (dark: destinations that were zero-filled once and are written by this kernel only - the engine's pyramids)
+    const bool dk = dark && ((dark[band] >> lane) & 1ull);
+    pw_load(s, w, h, wq, reflect101(2 * oy0 - 2, h), b0, pre[0], dk);
+    if (nin > 1) pw_load(s, w, h, wq, reflect101(2 * oy0 - 1, h), b0, pre[1], dk);
 
 #define PW_STEP(K)                                                                                              \
     if (i0 + (K) < nin) {                                                                                       \
         const int i = i0 + (K);                                                                                 \
         pw_hfilter(pre[(K) & 1], lane, jstar, R[(K) % 5]);                                                      \
-        if (i + 2 < nin) pw_load(s, w, h, wq, reflect101(2 * oy0 - 2 + i + 2, h), b0, pre[(K) & 1]);            \
+        if (i + 2 < nin) pw_load(s, w, h, wq, reflect101(2 * oy0 - 2 + i + 2, h), b0, pre[(K) & 1], dk);        \
         if (i >= 4 && !((K) & 1)) {                                                                             \
             uint32_t o[PW_DPL / 2];                                                                             \
             _Pragma("unroll") for (int m = 0; m < PW_DPL / 2; m++) {                                            \
@@ -286,7 +323,8 @@ __global__ __launch_bounds__(256) void pyr_down_wave_kernel(const uint8_t *__res
                 o[m] = __builtin_amdgcn_perm(sb, sa, 0x07050301u);                                              \
             }                                                                                                   \
             uint8_t *orow = d + (int64_t)(oy0 + ((i - 4) >> 1)) * dw + 2 * b0;                                  \
-            if (b0 + PW_DPL <= npair) *reinterpret_cast<u32x4_a4 *>(orow) = u32x4_a4{o[0], o[1], o[2], o[3]};   \
+            if (dk) { }                                                                                         \
+            else if (b0 + PW_DPL <= npair) *reinterpret_cast<u32x4_a4 *>(orow) = u32x4_a4{o[0], o[1], o[2], o[3]}; \
             else {                                                                                              \
                 _Pragma("unroll") for (int m = 0; m < PW_DPL / 2; m++)                                          \
                     if (b0 + 2 * m + 1 < npair) reinterpret_cast<uint32_t *>(orow)[m] = o[m];                   \
@@ -401,7 +439,7 @@ __global__ __launch_bounds__(256) void pyr_down2_rows_kernel(const uint8_t *__re
 }
 
 hipError_t launch_pyr_down(hipStream_t st, const uint8_t *src, int64_t src_lane_stride, int w, int h,
-                           uint8_t *dst, int64_t dst_lane_stride, int B)
+                           uint8_t *dst, int64_t dst_lane_stride, int B, const unsigned long long *dark)
 {
     const int dw = (w + 1) / 2, dh = (h + 1) / 2;
     const bool rows_ok = ((w & 3) == 0) && w >= 16 && w <= PR_MAXW && ((dw & 1) == 0) && ((src_lane_stride & 3) == 0) &&
@@ -412,7 +450,7 @@ hipError_t launch_pyr_down(hipStream_t st, const uint8_t *src, int64_t src_lane_
     if (wave_ok) {
         const int bands = (dh + PW_CH - 1) / PW_CH;
         hipLaunchKernelGGL(pyr_down_wave_kernel, dim3((bands + 3) / 4, B), dim3(256), 0, st, src, src_lane_stride, w, h, dst,
-                           dst_lane_stride, dw, dh, bands);
+                           dst_lane_stride, dw, dh, bands, dark);
         return hipGetLastError();
     }
     if (rows_ok) {
@@ -436,7 +474,7 @@ void pyr_desc_init(PyrDesc *d, int w, int h)
     d->lane_stride = off;
 }
 
-hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, int B)
+hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, int B, const unsigned long long *dark_l0)
 {
     for (int l = 0; l + 1 < ROAM_PYR_LEVELS; l++) {
         const int w = d.w[l], h = d.h[l], dw = d.w[l + 1], dh = d.h[l + 1];
@@ -452,7 +490,7 @@ hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, 
             l++;
             continue;
         }
-        hipError_t e = launch_pyr_down(st, pyr + d.off[l], d.lane_stride, w, h, pyr + d.off[l + 1], d.lane_stride, B);
+        hipError_t e = launch_pyr_down(st, pyr + d.off[l], d.lane_stride, w, h, pyr + d.off[l + 1], d.lane_stride, B, l == 0 ? dark_l0 : nullptr);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

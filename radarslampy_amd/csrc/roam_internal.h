@@ -107,8 +107,12 @@ struct PyrDesc {
 };
 void pyr_desc_init(PyrDesc *d, int w, int h);
 hipError_t launch_pyr_down(hipStream_t st, const uint8_t *src, int64_t src_lane_stride, int w, int h,
-                           uint8_t *dst, int64_t dst_lane_stride, int B);
-hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, int B);
+                           uint8_t *dst, int64_t dst_lane_stride, int B, const unsigned long long *dark = nullptr);
+// dark_l0 (optional, launch_pyr_dark): the lanes of the 2024 -> 1012 kernel whose pixels lie beyond the maximum range neither load nor
+// store - for pyramids that were zero-filled once and whose level 0 comes from launch_warp_gather(..., dark_stays_zero)
+hipError_t launch_build_pyramid(hipStream_t st, uint8_t *pyr, const PyrDesc &d, int B, const unsigned long long *dark_l0 = nullptr);
+size_t pyr_dark_words(int h);
+hipError_t launch_pyr_dark(hipStream_t st, const uint32_t *map, int w, int h, int cols, unsigned long long *dark);
 
 // KLT: pts/next: B x kstride x 2 f32; count[b] features per lane (or all K if count==null)
 hipError_t launch_klt(hipStream_t st, const uint8_t *prev_pyr, const uint8_t *next_pyr,
