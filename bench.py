@@ -534,7 +534,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
                        "workload_note": None if (args.no_retrack or args.endless or args.dry_engine) else
                                         "stationary by construction (streams of finite sequences): 46 % of the lanes re-detect in EVERY step and 29 % of the "
                                         "correspondences are rejected - harder than round 2's endless ping-pong, whose retrack rate decays with the steps played "
-                                        "(0.28 in the window the driver timed).  That workload is still here: `--endless --preroll 0 --distinct 4` = 67.0 k scan-pairs/s "
+                                        "(0.28 in the window the driver timed).  That workload is still here: `--endless --preroll 0 --distinct 4` = 67.7 k scan-pairs/s "
                                         "on this build against round 2's 53.2 k (profiles/r03_bench_round2_workload_20_5.json)",
                        "lanes_per_gpu": B, "engines_per_gpu": len(engs), "preroll_steps": pre,
                        "scans_per_step": B, "first_frame_scans_in_timed_steps": first_frames, "pairs_counted": (B * args.steps - first_frames), "h2d_streaming": bool(args.h2d), "frames": T, "distinct_sequences": Dn_,
