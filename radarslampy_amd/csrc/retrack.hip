@@ -8,8 +8,8 @@
 //                        first detection) take rt_integ_cols + rt_integ_rows instead: thousands of threads per detection
 //   K3 rt_det_strip      box-filter Hessian determinants of both live layers (sigma 5.005 / 10, sizes 15 / 30; the sigma 0.01 layer
 //                        is all-NaN in scikit-image and ignored): workgroups march down 62-column strips of the integral image with
-//                        its rows in an LDS ring (each byte fetched ~1.4 times); dxy boxes only where dxx*dyy can pass the
-//                        threshold; 3x3x3 maxima above the threshold are appended to the detection's candidate list
+//                        its rows in an LDS ring (each byte fetched ~1.4 times), over the steps of the strip that lie inside the
+//                        maximum range (a table, geometry only); dxy boxes only where dxx*dyy can pass the threshold; 3x3x3 maxima above the threshold are appended to the detection's candidate list
 //   K4 rt_emit           the candidates sorted into C (row, col, layer) order
 //   K5 rt_blobs          one wavefront per lane: response order, scikit-image's _prune_blobs in ITS pair order (blobprune.h:
 //                        cKDTree emission order + CPython set order; the tree is built level by level with one lane per node, the
@@ -1288,7 +1288,7 @@ size_t retrack_darktab_words(int W) { return (size_t)((W + SD_OUT - 1) / SD_OUT)
 hipError_t launch_retrack_darktab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *darktab)
 {
     const int ns = (W + SD_OUT - 1) / SD_OUT, nt = W / SD_T + 1;
-    if (nt > 256) return hipSuccess;                                         // (images above 4080 rows: nothing is skipped)
+    if (nt > 256) return hipErrorInvalidValue;                               // (the sampling map addresses 4095 range bins: W <= 4094, nt <= 256)
     hipLaunchKernelGGL(rt_darktab_kernel, dim3(ns, nt), dim3(256), 0, st, map, W, cols, darktab);
     hipLaunchKernelGGL(rt_darkskip_kernel, dim3(ns), dim3(256), 0, st, nt, darktab);
     return hipGetLastError();
