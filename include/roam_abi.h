@@ -94,9 +94,11 @@ int32_t roam_pyr_down_u8(roam_ctx *ctx, const uint8_t *src, int32_t w, int32_t h
 
 /* ---- a8: outlierRejection.rejectOutliers (outlierRejection.py:16-95) --------------------
  * prev/next (K,2) f32.  mask_out (K) u8 = membership of the maximum clique of the
- * |d_prev - d_next| <= thr_px consistency graph (lexicographically smallest maximum clique
- * when several exist).  node_limit bounds the branch-and-bound (0 = default);
- * *flags_out bit0 = search completed (result proven maximum). adj_out (optional) receives
+ * |d_prev - d_next| <= thr_px consistency graph; when several maximum cliques exist, the one
+ * the reference returns: the first strictly-largest clique in networkx.find_cliques order
+ * (outlierRejection.py:63-75; CPython set order restated on the device, csrc/clique.hip).
+ * node_limit bounds the branch-and-bound (0 = default); *flags_out bit0 = search completed
+ * (result proven maximum and equal to the reference's; otherwise the best clique found). adj_out (optional) receives
  * the K x ((K+63)/64) uint64 adjacency bit rows. */
 int32_t roam_reject_outliers(roam_ctx *ctx, const float *prev, const float *next, int32_t K,
                              double thr_px, int64_t node_limit, uint8_t *mask_out,

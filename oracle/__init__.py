@@ -217,13 +217,46 @@ def max_clique_lex(adj: np.ndarray):
     return size, mask.astype(bool), nodes.value
 
 
+def max_clique_nx(adj: np.ndarray, prune: bool = True):
+    """-> (size, mask, stats): the first strictly-largest clique in networkx.find_cliques order (the reference's choice,
+    outlierRejection.py:63-75); stats = (maximal cliques yielded, children skipped, existence searches, tree nodes)."""
+    K, nw = adj.shape
+    mask = np.zeros(max(K, 1), np.uint8)
+    stats = np.zeros(4, np.int64)
+    lib().oracle_max_clique_nx.restype = C.c_int
+    size = lib().oracle_max_clique_nx(_p(np.ascontiguousarray(adj), C.c_uint64), K, nw, int(bool(prune)),
+                                      _p(mask, C.c_uint8), _p(stats, C.c_int64))
+    return size, mask[:K].astype(bool), tuple(int(v) for v in stats)
+
+
+def max_cliques_nx_all(adj: np.ndarray, cap: int = 64):
+    """every maximum clique, in networkx.find_cliques order -> bool (n, K)"""
+    K, nw = adj.shape
+    masks = np.zeros((cap, max(K, 1)), np.uint8)
+    lib().oracle_max_cliques_nx_all.restype = C.c_int
+    n = lib().oracle_max_cliques_nx_all(_p(np.ascontiguousarray(adj), C.c_uint64), K, nw, _p(masks, C.c_uint8), cap)
+    return masks[:n, :K].astype(bool)
+
+
+def pyset_program(ops, keys, spans, out_cap=1 << 20):
+    """run a little program of CPython-set operations on the C restatement (tests/test_oracle_clique_order.py)"""
+    ops = np.ascontiguousarray(ops, np.int32).reshape(-1, 3)
+    keys = np.ascontiguousarray(keys, np.int32)
+    spans = np.ascontiguousarray(spans, np.int32).reshape(-1, 2)
+    out = np.zeros(out_cap, np.int32)
+    lib().oracle_pyset_program.restype = C.c_int64
+    n = lib().oracle_pyset_program(_p(ops, C.c_int32), len(ops), _p(keys, C.c_int32), _p(spans, C.c_int32), _p(out, C.c_int32), out_cap)
+    assert n <= out_cap
+    return out[:n]
+
+
 def rejectOutliers(prev_coord, new_coord):
-    """outlierRejection.py:16-95 -> (pruned_prev, pruned_new, mask bool (K,))."""
+    """outlierRejection.py:16-95 -> (pruned_prev, pruned_new, mask bool (K,)): the reference's clique, ties included."""
     assert prev_coord.shape == new_coord.shape, "Coordinates should be the same shape"
     K = prev_coord.shape[0]
     if K == 0:
         return prev_coord, new_coord, np.zeros(0, bool)
-    _, mask, _ = max_clique_lex(consistency_graph(prev_coord, new_coord))
+    _, mask, _ = max_clique_nx(consistency_graph(prev_coord, new_coord))
     return prev_coord[mask], new_coord[mask], mask
 
 

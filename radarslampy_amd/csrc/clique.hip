@@ -2,10 +2,10 @@
 //
 // Replaces outlierRejection.rejectOutliers (reference outlierRejection.py:16-95):
 //   A[i][j] = | ||p_i-p_j|| - ||n_i-n_j|| | <= thr  in float64 (scipy cdist), inliers = a
-//   maximum clique (networkx.find_cliques in the reference).  Result contract: the
-//   lexicographically smallest maximum clique (oracle/c/clique.c explains why the
-//   reference's own tie-break is not reproducible); equal to the reference's set whenever
-//   the maximum clique is unique, equal in size always (when the search completes).
+//   maximum clique.  Result contract: THE REFERENCE'S clique, ties included - the first strictly-largest clique in
+//   networkx.find_cliques order (outlierRejection.py:63-75).  That order is a deterministic property of networkx's
+//   iterative Bron-Kerbosch and of CPython's set (integer nodes hash to themselves); oracle/c/clique.c states both,
+//   nx_walk below re-creates them on the device.
 //
 // consistency_graph_kernel: one wavefront per 64 columns of one row; the 64 predicates
 //   become one adjacency word through a wave ballot.  float64 with explicit round-to-
@@ -217,6 +217,325 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- the reference's tie-break
+// rejectOutliers keeps the first strictly-largest clique that networkx.find_cliques yields.  find_cliques is an iterative
+// Bron-Kerbosch with Tomita pivoting on Python sets of ints, so its order is fixed by CPython's set: open addressing (slot
+// key & mask, 9 linear probes, then i*5+1+perturb), tables of 8 / 32 / 128 / 512 / 2048 slots as a set grows by insertion,
+// the smallest power of two above 2*len for a copy, iteration and pop() in slot order, "&" iterating the smaller operand.
+// nx_walk follows that tree with the SAME sets, but enters a child only when a clique of the size still needed exists among
+// its candidates (witness clique or cq_solve).  A child's sets are new objects in the reference, so skipping a subtree leaves
+// the parent's sets - and the order of everything after it - untouched; the first leaf of size omega is the reference's clique
+// and the walk never backtracks.
+//
+// A set = membership bits by KEY (word per lane) + the table layout.  Whenever every key is smaller than the table (always
+// true for the big sets: 77+ members live in 512 slots) each key sits in its own slot whatever the insertion history, the
+// iteration order is ascending and no table is kept ("ident").  Otherwise the insertion sequence is replayed: the probe
+// sequence only needs the OCCUPANCY of the table, held as one 64-slot word per lane and read with v_readlane, so an
+// insertion is a few scalar bit operations; the keys go to a small LDS table for later iteration.
+struct NxSet {
+    uint64_t live;      // members, bit per key
+    uint64_t occ;       // explicit layout: occupied slots (live or dummy), bit per slot
+    uint16_t *tab;      // explicit layout: slot -> key
+    int mask, used;
+    bool ident;
+};
+struct NxLds { uint16_t *tab[6], *seq, *seq2; int ts; };
+
+__host__ __device__ inline int nx_table_slots(int K)
+{
+    int ts = 8;                                     // an explicit table exists only when some key >= its size: size < K
+    while (ts * 2 < K && ts < 512) ts *= 2;
+    return ts;
+}
+__host__ __device__ inline size_t nx_lds_bytes(int K)
+{
+    return (((size_t)6 * nx_table_slots(K) + 2 * (size_t)(K + 2)) * sizeof(uint16_t) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int src)
+{
+    src = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int bs_last(uint64_t x)
+{
+    const uint64_t bal = __ballot(x != 0);
+    if (!bal) return -1;
+    const int hl = 63 - __clzll((long long)bal);
+    const uint64_t wv = rl64(x, hl);
+    return hl * 64 + 63 - __clzll((long long)wv);
+}
+__device__ __forceinline__ uint64_t bits_from(int lane, int first)      // keys / slots >= first
+{
+    const int w = first >> 6;
+    return lane > w ? ~0ull : (lane == w ? (~0ull << (first & 63)) : 0ull);
+}
+
+// slot an insertion of `key` takes in a table with occupancy `occ` (set_add_entry / set_insert_clean without dummies)
+__device__ __forceinline__ int nx_probe(uint64_t occ, int mask, int key)
+{
+    unsigned perturb = (unsigned)key, i = (unsigned)key & (unsigned)mask;
+    for (;;) {
+        const int lim = (i + 9 <= (unsigned)mask) ? 9 : 0;
+        const int w0 = (int)(i >> 6), sh = (int)(i & 63);
+        uint64_t win = rl64(occ, w0) >> sh;
+        if (sh + lim >= 64) win |= rl64(occ, w0 + 1) << (64 - sh);
+        const uint64_t fr = ~win & ((2ull << lim) - 1ull);
+        if (fr) return (int)i + __ffsll((long long)fr) - 1;
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (unsigned)mask;
+    }
+}
+
+// members of S that are in F, in S's iteration order -> seq[0..n); maxkey = the largest of them
+__device__ int nx_seq(const CqCtx &c, const NxSet &S, uint64_t F, uint16_t *seq, int &maxkey)
+{
+    const int lane = c.lane;
+    const uint64_t X = S.live & F;
+    maxkey = bs_last(X);
+    int n = 0;
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (S.ident) {
+        for (int w = 0; w < c.nw; w++) {
+            const uint64_t bits = rl64(X, w);
+            if (!bits) continue;
+            if ((bits >> lane) & 1ull) seq[n + __popcll(bits & below)] = (uint16_t)(w * 64 + lane);
+            n += __popcll(bits);
+        }
+    } else {
+        __syncthreads();
+        if (lane < 16) c.sw[lane] = X;
+        __syncthreads();
+        for (int ch = 0; ch * 64 <= S.mask; ch++) {
+            const uint64_t ob = rl64(S.occ, ch);
+            if (!ob) continue;
+            bool in = (ob >> lane) & 1ull;
+            int key = 0;
+            if (in) { key = S.tab[ch * 64 + lane]; in = (c.sw[key >> 6] >> (key & 63)) & 1ull; }
+            const uint64_t bal = __ballot(in);
+            if (in) seq[n + __popcll(bal & below)] = (uint16_t)key;
+            n += __popcll(bal);
+        }
+    }
+    __syncthreads();
+    return n;
+}
+
+// table of a set built by inserting seq[0..n) one by one (copy = false: growth 8 -> 32 -> 128 -> 512 -> 2048 as
+// set_add_entry resizes to used*4 once fill*5 >= mask*3) or in one go into the copy's table (copy = true: set_merge)
+__device__ void nx_build(const CqCtx &c, NxSet &D, const uint16_t *seq, int n, int maxkey, bool copy, uint16_t *tab, uint16_t *seq2)
+{
+    const int lane = c.lane;
+    int size = 8;
+    if (copy) { if (n >= 5) while (size <= 2 * n) size <<= 1; }
+    else size = n < 5 ? 8 : n < 19 ? 32 : n < 77 ? 128 : n < 307 ? 512 : 2048;
+    D.used = n; D.tab = tab; D.occ = 0; D.mask = size - 1;
+    D.ident = maxkey < size;
+    if (D.ident) return;
+    const uint64_t below = (1ull << lane) - 1ull;
+    int mask = copy ? size - 1 : 7, fill = 0;
+    uint64_t occ = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int kv = (i0 + lane < n) ? (int)seq[i0 + lane] : 0;
+        const int m = min(64, n - i0);
+        for (int j = 0; j < m; j++) {
+            const int key = __builtin_amdgcn_readlane(kv, j);
+            const int slot = nx_probe(occ, mask, key);
+            if (lane == 0) tab[slot] = (uint16_t)key;
+            if (lane == (slot >> 6)) occ |= 1ull << (slot & 63);
+            fill++;
+            if (!copy && fill * 5 >= mask * 3) {                        // set_table_resize(used * 4): re-insert in slot order
+                int ns = 8;
+                while (ns <= fill * 4) ns <<= 1;
+                __syncthreads();
+                int cnt = 0;
+                for (int ch = 0; ch * 64 <= mask; ch++) {
+                    const uint64_t ob = rl64(occ, ch);
+                    if (!ob) continue;
+                    if ((ob >> lane) & 1ull) seq2[cnt + __popcll(ob & below)] = tab[ch * 64 + lane];
+                    cnt += __popcll(ob);
+                }
+                __syncthreads();
+                occ = 0; mask = ns - 1;
+                for (int r0 = 0; r0 < cnt; r0 += 64) {
+                    const int rv = (r0 + lane < cnt) ? (int)seq2[r0 + lane] : 0;
+                    const int rm = min(64, cnt - r0);
+                    for (int r = 0; r < rm; r++) {
+                        const int k2 = __builtin_amdgcn_readlane(rv, r);
+                        const int s2 = nx_probe(occ, mask, k2);
+                        if (lane == 0) tab[s2] = (uint16_t)k2;
+                        if (lane == (s2 >> 6)) occ |= 1ull << (s2 & 63);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    D.occ = occ; D.mask = mask;
+}
+
+// D = {x in ITER's order if x in F}: set_intersection / the iterating branch of set_difference
+__device__ void nx_filter_build(const CqCtx &c, NxLds &L, NxSet &D, const NxSet &ITER, uint64_t F, uint16_t *tab)
+{
+    int maxkey;
+    const int n = nx_seq(c, ITER, F, L.seq, maxkey);
+    D.live = ITER.live & F;
+    nx_build(c, D, L.seq, n, maxkey, false, tab, L.seq2);
+}
+
+// adj[q] = {v for v in G[q] if v != q}: ascending insertion of the row
+__device__ void nx_adj_set(const CqCtx &c, NxLds &L, NxSet &D, uint64_t row, uint16_t *tab)
+{
+    NxSet asc; asc.live = row; asc.ident = true; asc.mask = 0; asc.used = 0; asc.occ = 0; asc.tab = nullptr;
+    nx_filter_build(c, L, D, asc, ~0ull, tab);
+}
+
+// S & adj[q] (either operand order: the smaller one is iterated, adj[q] on equal sizes)
+__device__ void nx_and_adj(const CqCtx &c, NxLds &L, NxSet &D, const NxSet &S, int slen, uint64_t row, int deg, uint16_t *tab)
+{
+    if (deg > slen) { nx_filter_build(c, L, D, S, row, tab); return; }
+    NxSet A;
+    nx_adj_set(c, L, A, row, L.tab[4]);
+    nx_filter_build(c, L, D, A, S.live, tab);
+}
+
+// pivot = max(subg, key = |cand & adj[u]|), the FIRST maximum in subg's iteration order
+__device__ int nx_pivot(const CqCtx &c, const NxSet &SG, uint64_t candbits)
+{
+    const int lane = c.lane;
+    __syncthreads();
+    if (lane < 16) c.sw[lane] = candbits;
+    __syncthreads();
+    int best = -1;                                                      // (count << 12) | (4095 - position), then the key
+    int bestu = 0;
+    const int chunks = SG.ident ? c.nw : (SG.mask >> 6) + 1;
+    for (int ch = 0; ch < chunks; ch++) {
+        const uint64_t bits = rl64(SG.ident ? SG.live : SG.occ, ch);
+        if (!bits) continue;
+        if (!((bits >> lane) & 1ull)) continue;
+        const int pos = ch * 64 + lane;
+        const int u = SG.ident ? pos : (int)SG.tab[pos];
+        int d = 0;
+        for (int w = 0; w < c.nw; w++) d += __popcll(c.A[(int64_t)u * c.as + w] & c.sw[w]);
+        const int key = (d << 12) | (4095 - pos);
+        if (key > best) { best = key; bestu = u; }
+    }
+    int m = best;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    const uint64_t who = __ballot(best == m);
+    const int src = __ffsll((long long)who) - 1;
+    __syncthreads();
+    return __shfl(bestu, src);
+}
+
+// ext_u = cand - adj[u]
+__device__ void nx_sub_adj(const CqCtx &c, NxLds &L, NxSet &E, const NxSet &CD, uint64_t row, int deg)
+{
+    const int lane = c.lane;
+    if ((CD.used >> 2) > deg) {                                         // set_copy_and_difference (cand is fresh here: no dummies)
+        int size = 8;
+        if (CD.used >= 5) while (size <= 2 * CD.used) size <<= 1;
+        if (size - 1 == CD.mask) {                                      // same table size: slot-for-slot copy
+            E = CD; E.tab = L.tab[5];
+            if (!CD.ident) { for (int i = lane; i <= CD.mask; i += 64) L.tab[5][i] = CD.tab[i]; __syncthreads(); }
+        } else {
+            int maxkey;
+            const int n = nx_seq(c, CD, ~0ull, L.seq, maxkey);
+            E.live = CD.live;
+            nx_build(c, E, L.seq, n, maxkey, true, L.tab[5], L.seq2);
+        }
+        E.live &= ~row;                                                 // discards leave dummies: the layout stays
+        E.used = bs_count(E.live);
+        return;
+    }
+    nx_filter_build(c, L, E, CD, ~row, L.tab[5]);
+}
+
+// q = ext_u.pop(): the first live slot (the finger only ever moves forward here)
+__device__ int nx_pop(const CqCtx &c, NxSet &E)
+{
+    const int lane = c.lane;
+    int q;
+    if (E.ident) q = bs_first(E.live);
+    else {
+        q = -1;
+        for (int ch = 0; ch * 64 <= E.mask && q < 0; ch++) {
+            uint64_t ob = rl64(E.occ, ch);
+            while (ob) {
+                const int sl = __ffsll((long long)ob) - 1;
+                ob &= ob - 1;
+                const int key = E.tab[ch * 64 + sl];
+                const bool alive = __ballot((E.live & bit_if(lane, key)) != 0) != 0;
+                if (lane == ch) E.occ &= ~(1ull << sl);                  // popped or already a dummy: never looked at again
+                if (alive) { q = key; break; }
+            }
+        }
+    }
+    if (q >= 0) { E.live &= ~bit_if(lane, q); E.used--; }
+    return q;
+}
+
+// RF = the first clique of size omega in networkx.find_cliques order.  false: the bounded searches ran out of nodes.
+__device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uint64_t WIT, uint64_t &RF)
+{
+    const int lane = c.lane, nw = c.nw;
+    NxSet subg, cand, ext;
+    int cur = 0;
+    cand.live = ALL; cand.ident = true; cand.used = Kb; cand.occ = 0; cand.tab = L.tab[2];                     // set(G): every key < table size
+    cand.mask = (Kb < 5 ? 8 : Kb < 19 ? 32 : Kb < 77 ? 128 : Kb < 307 ? 512 : 2048) - 1;
+    subg = cand; subg.tab = L.tab[0];                                                                          // cand.copy(): likewise
+    {
+        const int pu = nx_pivot(c, subg, cand.live);
+        const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
+        nx_sub_adj(c, L, ext, cand, prow, bs_count(prow));
+    }
+    RF = 0;
+    int size = 0;
+    for (;;) {
+        const int q = nx_pop(c, ext);
+        if (q < 0) return false;                                        // cannot happen while the existence answers are exact
+        const uint64_t bq = bit_if(lane, q);
+        if (cand.live & bq) { cand.live &= ~bq; }                       // cand.remove(q): a dummy stays in its slot
+        cand.used--;
+        const uint64_t row = (lane < nw) ? c.A[(int64_t)q * c.as + lane] : 0ull;
+        const uint64_t Sq = subg.live & row, Cq = cand.live & row;
+        const int s1 = size + 1;
+        if (!__ballot(Sq != 0)) {                                       // maximal clique Q + q
+            if (s1 >= omega) { RF |= bq; return true; }
+            continue;
+        }
+        const int ncq = bs_count(Cq);
+        if (ncq == 0) continue;
+        const int need = omega - s1;
+        if (need <= 0) { RF |= bq; return true; }
+        if (ncq < need) continue;
+        const uint64_t QB = RF | bq;
+        bool ok = !__ballot((QB & ~WIT) != 0) && !__ballot((WIT & ~QB & ~Cq) != 0);      // the witness lives in this subtree
+        if (!ok) {
+            uint64_t RQ = 0;
+            const int got = cq_solve(c, Cq, need - 1, need, RQ);
+            if (!c.complete) return false;
+            if (got >= need) { ok = true; WIT = QB | RQ; }
+        }
+        if (!ok) continue;
+        // descend: subg_q = subg & adj[q], cand_q = cand & adj[q], the new pivot and ext_u
+        const int deg = bs_count(row);
+        NxSet nsub, ncand;
+        nx_and_adj(c, L, nsub, subg, subg.used, row, deg, L.tab[cur ^ 1]);
+        nx_and_adj(c, L, ncand, cand, cand.used, row, deg, L.tab[2 + (cur ^ 1)]);
+        subg = nsub; cand = ncand; cur ^= 1;
+        RF = QB; size = s1;
+        const int pu = nx_pivot(c, subg, cand.live);
+        const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
+        nx_sub_adj(c, L, ext, cand, prow, bs_count(prow));
+    }
+}
+
 __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restrict__ adj_g,
                                                         const int32_t *__restrict__ count, int K, int kstride,
                                                         int nws, long long node_limit,
@@ -233,11 +552,12 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
         return;
     }
     const int nw = (Kb + 63) >> 6;                 // active words per bitset
-    // ---- LDS carve: three short[K+2] level arrays, sw[16] u64, adjacency (compact stride)
+    // ---- LDS carve: three short[K+2] level arrays, sw[16] u64, the walk's tables, adjacency (compact stride)
     short *lsize = reinterpret_cast<short *>(cq_smem);
     short *lv = lsize + (K + 2), *lstage = lv + (K + 2);
     uint64_t *sw = reinterpret_cast<uint64_t *>(cq_smem + ((3 * sizeof(short) * (K + 2) + 15) & ~(size_t)15));
-    uint64_t *adj_l = sw + 16;
+    unsigned char *nx_mem = reinterpret_cast<unsigned char *>(sw + 16);        // the walk's tables and lists (nx_lds_bytes)
+    uint64_t *adj_l = reinterpret_cast<uint64_t *>(nx_mem + nx_lds_bytes(K));
     const uint64_t *Ag = adj_g + (int64_t)b * kstride * nws;
     const bool use_lds = (Kb * nw <= CQ_LDS_ADJ_WORDS);
     CqCtx c;
@@ -263,32 +583,18 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
     // ---- phase 1: omega and one maximum clique (the witness)
     uint64_t WIT = 0;
     const int omega = cq_solve(c, ALL, 0, 0x7fffffff, WIT);
-    // ---- phase 2: the lexicographically smallest maximum clique.  Vertices are fixed in ascending order; v is taken iff
-    // a clique of the size still needed exists among the common neighbours above it.  The witness (a maximum clique that
-    // extends the choices made so far) answers "yes" for its own members without a search; every other vertex costs one
-    // bounded existence query, and a successful query replaces the witness.
-    uint64_t C = ALL, RF = 0;
-    int need = omega;
-    while (need > 0 && c.complete) {
-        const int v = bs_first(C);
-        if (v < 0) break;                                               // cannot happen for an exact omega
-        const uint64_t bv = bit_if(lane, v);
-        const uint64_t row = (lane < nw) ? c.A[(int64_t)v * c.as + lane] : 0ull;
-        const uint64_t S = C & row;                                    // C holds only vertices above the last decision
-        const bool inwit = __ballot((WIT & bv) != 0) != 0;
-        bool take = inwit;
-        if (!take && bs_count(S) >= need - 1) {
-            if (need == 1) { take = true; WIT = RF | bv; }
-            else {
-                uint64_t RQ = 0;
-                const int got = cq_solve(c, S, need - 2, need - 1, RQ);
-                if (got >= need - 1) { take = true; WIT = RF | bv | RQ; }
-            }
-        }
-        if (take) { RF |= bv; C = S; need--; }
-        else C &= ~bv;
+    // ---- phase 2: the first clique of size omega in networkx.find_cliques order (nx_walk)
+    uint64_t REC = WIT;
+    if (c.complete && omega > 0) {
+        NxLds L;
+        L.ts = nx_table_slots(K);
+        uint16_t *base = reinterpret_cast<uint16_t *>(nx_mem);
+        for (int t = 0; t < 6; t++) L.tab[t] = base + t * L.ts;
+        L.seq = base + 6 * L.ts;
+        L.seq2 = L.seq + (K + 2);
+        uint64_t RF = 0;
+        if (nx_walk(c, L, Kb, ALL, omega, WIT, RF)) REC = RF;
     }
-    const uint64_t REC = (c.complete && need == 0) ? RF : WIT;          // incomplete search: the best clique known
 
     // ---- emit
     if (lane < 16) sw[lane] = REC;
@@ -305,7 +611,7 @@ hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t 
                              uint8_t *mask, int32_t *n_in, int32_t *flags)
 {
     if (B <= 0 || K <= 0) return hipSuccess;
-    size_t lds = ((3 * sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 16 * 8;
+    size_t lds = ((3 * sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 16 * 8 + nx_lds_bytes(K);
     const size_t kw = (size_t)K * ((K + 63) / 64);
     lds += 8 * (kw < CQ_LDS_ADJ_WORDS ? kw : (size_t)CQ_LDS_ADJ_WORDS);
     if (node_limit <= 0) node_limit = 300000;

@@ -1,6 +1,6 @@
 """Consistency-graph outlier rejection (reference outlierRejection.py:10-95) on the MI355X
-(clique.hip): maximum clique of the |d_prev - d_new| <= 0.5 m graph; the lexicographically
-smallest maximum clique when several exist (the reference's own tie-break is not reproducible)."""
+(clique.hip): maximum clique of the |d_prev - d_new| <= 0.5 m graph; when several maximum cliques
+exist, the one the reference returns - the first in networkx.find_cliques order (outlierRejection.py:63-75)."""
 import numpy as np
 
 from . import _ffi

@@ -1,0 +1,56 @@
+"""GPU twin of tests/test_oracle_tiny_traj.py: the HIP engine (one lane, device-side detection and retracks, the device's
+networkx-order clique) over the reference's 11 real data/tiny scans from the ground-truth start pose, against the numbers the
+REFERENCE ITSELF printed into img/roam_mapping/tiny_traj/00NN.jpg (fixture tests/golden/tiny_traj.npz): frames 1-3 to print
+precision (1e-3 m, 1e-3 deg), every frame equal to the oracle's loop body within the north_star tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+PRINT = 1.1e-3
+
+
+def test_engine_reproduces_the_reference_prints_on_data_tiny():
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    traj = np.load(os.path.join(HERE, "golden", "tiny_traj.npz"))
+    pay = np.load(os.path.join(HERE, "golden", "tiny_track.npz"))["payload"]
+    T, rows, clip = pay.shape
+    det = lambda c: oracle.getFeatures(c)[0]                                    # noqa: E731
+    ctx = _ffi.Context(0)
+    eng = Engine(1, T, ctx=ctx, rows=rows, stride=clip, payload_off=0, clip=clip, retrack_on_device=True)
+    for t in range(T):
+        eng.upload_scan(t, np.ascontiguousarray(pay[t]))
+    pose0 = traj["gt_pose"][0]
+    eng.init_lane_detect(0, 0, pose0)
+    cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), det(cart0))
+    pipe = oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), feat0, pose0, detect=det, payload_off=0, clip=clip)
+    est = [pose0]
+    retracks = []
+    for t in range(1, T):
+        eng.step([t])
+        got = eng.results()[0]
+        want = pipe.step(np.ascontiguousarray(pay[t]))
+        assert (got["n_tracked"], got["n_good"], got["n_inliers"]) == (want["n_tracked"], want["n_good"], want["n_inliers"]), t
+        assert got["clique_proven"], t
+        assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= 1e-4 and abs(got["pose"][2] - want["pose"][2]) <= 1e-5, t
+        est.append(np.array(got["pose"]))
+        printed = np.array([got["pose"][0], got["pose"][1], np.rad2deg(got["pose"][2])])
+        d = np.abs(printed - traj["roam_mapping_est_pose"][t - 1])
+        rmse = float(np.sqrt(np.mean(((traj["gt_pose"][:t + 1, :2] - np.array(est)[:, :2]) ** 2).sum(1))))
+        if t <= 3:
+            assert d.max() <= PRINT, (t, printed, traj["roam_mapping_est_pose"][t - 1])          # the reference's own print
+            assert abs(rmse - traj["roam_mapping_rmse"][t - 1]) <= 5.1e-3, t
+        else:
+            assert d[:2].max() < 0.15 and d[2] < 0.3, (t, d)                                      # frame 4 on
+            assert abs(rmse - traj["roam_mapping_rmse"][t - 1]) < 0.02, t
+        if got["retrack"]:
+            retracks.append(t)
+    assert retracks == [1, 2, 4, 7, 9], retracks           # the frames whose reference picture shows freshly appended features
+    eng.close()
+    ctx.close()

@@ -1,0 +1,130 @@
+"""END TO END against the reference's OWN pose outputs on data/tiny: the numbers RawROAMSystem printed into
+img/roam_mapping/tiny_traj/00NN.jpg (fixture tests/golden/tiny_traj.npz, made and digit-by-digit verified by
+tests/golden/make_tiny_traj.py) vs the oracle's loop body (oracle.OdometryPipeline) over the same 11 scans from the same
+ground-truth start pose.  Print precision: 1e-3 m, 1e-3 deg (1.7e-5 rad), RMSE 1e-2.
+
+What is reproduced, and what is not (DESIGN.md section 4 has the table):
+  frames 1-3   EST Pose, EST Deltas and RMSE to print precision - with the reference's clique tie-break (4-, 14- and 2-way ties
+               between maximum cliques on these pairs; the lexicographic rule of rounds 1-3 was 2-10 mm off on frame 1);
+  frame 4      the reference's numbers are those of the SECOND of the nine tied maximum cliques in networkx order on our
+               graph (shown below by enumerating the nine); with it frame 5 follows to print precision;
+  frames 6-10  the reference's run holds a feature set ours does not (no clique of our frame-6 graph gives its pose); the
+               poses stay within 0.15 m / 0.3 deg and the RMSE within 0.02 of the reference's.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PRINT = 1.1e-3                      # half a unit of the third decimal + float noise on either side
+
+
+@pytest.fixture(scope="module")
+def data():
+    traj = np.load(os.path.join(HERE, "golden", "tiny_traj.npz"))
+    pay = np.load(os.path.join(HERE, "golden", "tiny_track.npz"))["payload"]
+    return traj, pay
+
+
+def _detect(cart):
+    return oracle.getFeatures(cart)[0]
+
+
+def _pipeline(traj, pay, motion_distortion=True):
+    cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), _detect(cart0))
+    return oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), feat0, traj["gt_pose"][0], detect=_detect, payload_off=0,
+                                   clip=pay.shape[2], motion_distortion=motion_distortion)
+
+
+def _printed(pose):
+    return np.array([pose[0], pose[1], np.rad2deg(pose[2])])
+
+
+def _deltas(prev_pose, pose):
+    """convertRandHtoDeltas of T_prev^-1 T_new (RawROAMSystem.py:211-213, 428-429)"""
+    T = np.linalg.inv(oracle.convertPoseToTransform(prev_pose)) @ oracle.convertPoseToTransform(pose)
+    return np.array([T[0, 2], T[1, 2], np.rad2deg(np.arctan2(T[1, 0], T[0, 0]))])
+
+
+def _rmse(gt, est):
+    return float(np.sqrt(np.mean(((gt[:, :2] - np.asarray(est)[:, :2]) ** 2).sum(1))))
+
+
+def test_frames_1_to_3_reproduce_the_reference_prints(data):
+    traj, pay = data
+    pipe = _pipeline(traj, pay)
+    est = [traj["gt_pose"][0]]
+    for t in (1, 2, 3):
+        out = pipe.step(np.ascontiguousarray(pay[t]))
+        est.append(out["pose"].copy())
+        assert np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1]).max() <= PRINT, t
+        assert np.abs(_deltas(est[-2], est[-1]) - traj["roam_mapping_est_deltas"][t - 1]).max() <= PRINT, t
+        assert abs(_rmse(traj["gt_pose"][:t + 1], est) - traj["roam_mapping_rmse"][t - 1]) <= 5.1e-3, t
+
+
+def test_frame_4_is_the_second_tied_clique_and_frame_5_follows(data, monkeypatch):
+    traj, pay = data
+    pipe = _pipeline(traj, pay)
+    for t in (1, 2, 3):
+        pipe.step(np.ascontiguousarray(pay[t]))
+    import copy
+    base = copy.deepcopy({k: v for k, v in pipe.__dict__.items() if k != "detect"})
+    first = pipe.step(np.ascontiguousarray(pay[4]))
+    d_first = np.abs(_printed(first["pose"]) - traj["roam_mapping_est_pose"][3])
+    assert d_first[:2].max() > 0.01                                       # our first clique: 16 / 27 mm, 0.03 deg away
+
+    found = {}
+    real = oracle.rejectOutliers
+
+    def pick(k):
+        def rej(prev, new):
+            masks = oracle.max_cliques_nx_all(oracle.consistency_graph(prev, new))
+            found["n"] = len(masks)
+            m = masks[min(k, len(masks) - 1)]
+            return prev[m], new[m], m
+        return rej
+
+    hits = []
+    for k in range(9):
+        p2 = oracle.OdometryPipeline.__new__(oracle.OdometryPipeline)
+        p2.__dict__.update(copy.deepcopy(base))
+        p2.detect = _detect
+        monkeypatch.setattr(oracle, "rejectOutliers", pick(k))
+        out = p2.step(np.ascontiguousarray(pay[4]))
+        if np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][3]).max() <= PRINT:
+            hits.append(k)
+            monkeypatch.setattr(oracle, "rejectOutliers", real)
+            nxt = p2.step(np.ascontiguousarray(pay[5]))
+            assert np.abs(_printed(nxt["pose"]) - traj["roam_mapping_est_pose"][4]).max() <= PRINT
+    monkeypatch.setattr(oracle, "rejectOutliers", real)
+    assert found["n"] == 9 and hits == [1], (found, hits)
+
+
+def test_frames_6_to_10_stay_in_the_neighbourhood(data):
+    traj, pay = data
+    pipe = _pipeline(traj, pay)
+    est = [traj["gt_pose"][0]]
+    for t in range(1, 11):
+        out = pipe.step(np.ascontiguousarray(pay[t]))
+        est.append(out["pose"].copy())
+        d = np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1])
+        assert d[:2].max() < 0.15 and d[2] < 0.3, (t, d)
+        assert abs(_rmse(traj["gt_pose"][:t + 1], est) - traj["roam_mapping_rmse"][t - 1]) < 0.02, t
+    # the retrack frames of the reference's run are the frames whose picture shows the freshly appended features: 1, 2, 4, 7, 9
+
+
+def test_the_other_two_picture_sets_are_other_revisions(data):
+    """img/roam (dead reckoning, an earlier revision) and img/dead_reckoning (legacy driver with a random RANSAC): HEAD's loop with
+    motion distortion off lands in their neighbourhood but does not reproduce them - recorded, not chased"""
+    traj, pay = data
+    pipe = _pipeline(traj, pay, motion_distortion=False)
+    for t in range(1, 11):
+        out = pipe.step(np.ascontiguousarray(pay[t]))
+    d = np.abs(_printed(out["pose"]) - traj["roam_est_pose"][9])
+    assert d[:2].max() < 0.6 and d[2] < 0.5, d
+    assert np.abs(traj["roam_gt_deltas"] - traj["roam_mapping_gt_deltas"]).max() == 0          # same ground truth in both sets
+    assert np.abs(traj["dead_reckoning_gt_deltas"][:, :2] - traj["roam_gt_deltas"][1:, :2]).max() <= 5.01e-4
