@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--h2d", action="store_true", help="stream every scan from pinned host memory over PCIe (double-buffered pool); reports the PCIe-inclusive rate")
     ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
     ap.add_argument("--force-comm", action="store_true", help="create the RCCL communicator even at world size 1 (exercises the collective path on a 1-GPU box)")
+    ap.add_argument("--no-segments", action="store_true", help="skip the extra segments of the default run (endless ping-pong steps, single-sequence streaming)")
     ap.add_argument("--dry-engine", action="store_true", help="CPU stub instead of the GPU engine: exercises launcher / rendezvous / reduction only")
     args = ap.parse_args(argv)
     if args.lanes is None:
@@ -265,6 +266,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
     B, T, Dn_ = args.lanes, args.frames, max(1, min(args.distinct, args.lanes))
     cyc = list(range(1, T)) + list(range(T - 2, -1, -1))           # ping-pong frame schedule 1,2,..,T-1,T-2,..,0,1,..
     retracks_per_step = []
+    stream_recs = None
 
     if args.dry_engine:
         eng = DryEngine(B, rank)
@@ -278,6 +280,8 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         # the feature re-detection (DoH + ANMS) is part of the timed loop at the cadence the data dictates
         WORK = WORK_STEADY if args.no_retrack else WORK_RETRACK
         seqs = render_sequences([1000 * rank + 17 * d + 5 for d in range(Dn_)], T, not args.no_md, WORK, args.render_procs)
+        if rank == 0 and world == 1 and not (args.no_segments or args.no_retrack or args.h2d or args.no_md):
+            stream_recs = stream_render(args, True)                # the --stream segment's records, before the GPU is touched
         from radarslampy_amd import _ffi
         from radarslampy_amd.engine import Engine
         ctx = _ffi.Context(local_rank)
@@ -497,6 +501,8 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         for _ in range(1):
             step_all(s, False); s += 1
         barrier()
+        for en in engs:
+            en.results_array()                                  # latest records: the engine shrinks its launch width back to what the lanes hold
         k2, trk = 2, []
         t1 = time.perf_counter()
         for _ in range(k2):
@@ -512,6 +518,24 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         for en in engs:
             en.set_retrack(1)
         extra["stage_ms_last_mix_step"] = {k: round(v, 4) for k, v in stage_mix.items()}
+        if not args.no_segments and not args.endless:
+            # round 2's workload on the same clock: every lane keeps playing its ping-pong sequence, no new sequences (the retrack
+            # rate then decays with the steps played: ENDLESS_STEPS steps after ENDLESS_WARM untimed ones from the mix's state)
+            for _ in range(ENDLESS_WARM):
+                step_all(s, False); s += 1
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(ENDLESS_STEPS):
+                step_all(s, False); s += 1
+            barrier()
+            dt2 = time.perf_counter() - t2
+            nrt = 0
+            for en in engs:
+                for q in range(min(ENDLESS_STEPS, 8)):
+                    nrt += int(np.count_nonzero(en.results_array(en.steps_enqueued() - 1 - q)["flags"] & 8))
+            extra["endless_pairs_per_s"] = round(B * ENDLESS_STEPS / dt2, 1)
+            extra["endless_retrack_fraction_last_steps"] = round(nrt / (B * min(ENDLESS_STEPS, 8)), 4)
+            extra["endless_segment"] = f"{ENDLESS_STEPS} timed steps after {ENDLESS_WARM} untimed ones, no new sequences (round 2's workload shape), same lanes"
 
     out = None
     if rank == 0:
@@ -555,7 +579,13 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             out["config"].update(extra)
             if not extra:
                 out["config"]["stage_ms_last_step"] = {k: round(v, 4) for k, v in eng.stage_times().items()}
-            out["config"]["whole_path_Bmin_GBs_per_gpu"] = round(13.07e6 * (value / world) / 1e9, 3)   # SURVEY 8d B_min per steady pair
+            out["config"]["whole_path_Bmin_GBs_per_gpu"] = round(13.07e6 * (value / world) / 1e9, 3)   # SURVEY 8d B_min per steady pair ONLY
+            # steady bytes of every scan + the strict bytes of every re-detection (polar payload + f64 integral image written, then read
+            # once: 66.4 MB) over the step time: what the whole step moves algorithmically
+            if rps:
+                W_ = 2 * (eng.cfg.clip // 2)
+                det_bytes = eng.cfg.rows * eng.cfg.clip + 2 * 8.0 * W_ * W_
+                out["config"]["whole_step_algorithmic_GBs"] = round((13.07e6 * B + det_bytes * float(np.mean(rps))) / (dt / args.steps) / 1e9, 1)
             out["roofline"] = roofline(eng, args, B, out["config"].get("retrack_fraction") or 0.0, live)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, seqs, cyc)
@@ -565,10 +595,23 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
         comm.close()
     for c in ctxs:
         c.close()
+    if out is not None and stream_recs is not None:
+        # BASELINE configs 3 / 4 on the same clock: ONE sequence through a 1-lane engine (records rendered before the timed region)
+        from radarslampy_amd import _ffi
+        sctx = _ffi.Context(local_rank)
+        for md_ in (True, False):
+            _, cfg_ = stream_measure(stream_recs[0], stream_recs[1], md_, sctx)
+            tag = "md_on" if md_ else "md_off"
+            out["config"][f"stream_pairs_per_s_{tag}"] = cfg_["pipelined_pairs_per_s"]
+            out["config"][f"stream_ms_per_pair_awaited_{tag}"] = cfg_["latency_ms_per_pair"]["median"]
+            out["config"][f"stream_ms_retrack_pair_awaited_{tag}"] = cfg_["latency_ms_per_pair"]["median_retrack_pair"]
+        out["config"]["stream_segment"] = f"{len(stream_recs[0])} frames along full_seq_1's ground-truth motions, 1 lane, pinned ring + result ring; = python bench.py --stream [--no-md]"
+        sctx.close()
     if out is not None:
         print(json.dumps(out), flush=True)
 
 
+ENDLESS_WARM, ENDLESS_STEPS = 5, 20
 HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: what streaming kernels reach
 
 
@@ -647,9 +690,16 @@ def roofline(eng, args, B, retrack_fraction, live_all):
             lds_frac = rec["lds_active_cycles_per_launch"] / (256 * CLOCK_HZ * iso_s)
         detail = rec.get("note")
     iso_frac = iso[dom][1] / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    # the sampling-map words the integral kernel also reads (4 B per pixel, the same table for every detection, mostly L2 hits):
+    # shown, never part of `achieved`
+    W_ = 2 * (eng.cfg.clip // 2)
+    map_bytes = int(units * W_ * W_ * 4) if dom == "doh_integral" else 0
     return {"bound": "hbm", "bound_detail": detail, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": src,
             "traffic_over_algorithmic": None if not traffic else round(traffic / algo_bytes, 3),
+            "algorithmic_bytes_strict": algo_bytes, "algorithmic_bytes_incl_shared_map": algo_bytes + map_bytes,
+            "frac_incl_shared_map": round((algo_bytes + map_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "hbm_frac_measured": None if not traffic else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "isolated_busy_fractions": {"hbm_of_6.3TBs_corrected_traffic": None if mem_frac is None else round(mem_frac, 3),
                                         "valu_issue": None if valu_frac is None else round(valu_frac, 3),
                                         "lds_array": None if lds_frac is None else round(lds_frac, 3)},
@@ -707,15 +757,10 @@ def cpu_baseline(args, seqs, cyc):
     return cpu
 
 
-def run_stream(args):
-    """BASELINE configs 3 / 4 as the reference runs them: ONE sequence (full_seq_1-like motion, unbounded reflector world with
-    movers, scintillation and, with motion distortion on, intra-scan distortion) through a 1-lane engine - frames from a pinned
-    ring on the copy stream, poses through the result ring.  (i) pipelined: steps enqueued as fast as the rings allow = engine-only
-    scan pairs/s of one sequence; (ii) latency: every pose awaited before the next frame is stepped."""
-    from radarslampy_amd import _ffi, synth
-    from radarslampy_amd.RawROAMSystem import stream_records
+def stream_render(args, md):
+    """records + ground-truth poses of the --stream sequence (rendered by a pool of host processes, before the GPU is touched)"""
+    from radarslampy_amd import synth
     n = args.stream_frames
-    md = not args.no_md
     gold = os.path.join(ROOT, "tests", "golden", "full_seq_1_gt_deltas.npz")
     deltas = np.load(gold)["deltas"][args.stream_start:args.stream_start + n - 1]
     poses = synth.poses_from_deltas(deltas)
@@ -729,8 +774,13 @@ def run_stream(args):
     except BaseException:
         pool.terminate()
         raise
-    ctx = _ffi.Context(0)
-    info = ctx.device_info()
+    return recs, poses
+
+
+def stream_measure(recs, poses, md, ctx):
+    """one sequence through a 1-lane engine: (i) pipelined, (ii) every pose awaited before the next frame is stepped"""
+    from radarslampy_amd.RawROAMSystem import stream_records
+    n = len(recs)
     flags = {"rejectOutliers": True, "correctMotionDistortion": md}
     stream_records(iter(recs[:12]), 12, poses[0], flags, ctx)                   # warm-up (allocations, first launches)
     t0 = time.perf_counter()
@@ -740,25 +790,40 @@ def run_stream(args):
     est2, log2, lat = stream_records(iter(recs), n, poses[0], flags, ctx, synchronous=True)
     dt2 = time.perf_counter() - t1
     assert est.tobytes() == est2.tobytes()
-    ctx.close()
     lat = np.array(lat) * 1e3
     rt = np.array([e["retrack"] for e in log], bool)
     err = np.hypot(*(est[:, :2] - poses[1:, :2]).T)
+    return dt, {"frames": n,
+                "pipelined_pairs_per_s": round((n - 1) / dt, 2),
+                "synchronous_pairs_per_s": round((n - 1) / dt2, 2),
+                "latency_ms_per_pair": {"median": round(float(np.median(lat)), 3), "p95": round(float(np.percentile(lat, 95)), 3), "max": round(float(lat.max()), 3),
+                                        "median_steady_pair": round(float(np.median(lat[~rt])), 3) if (~rt).any() else None,
+                                        "median_retrack_pair": round(float(np.median(lat[rt])), 3) if rt.any() else None},
+                "retrack_fraction": round(float(rt.mean()), 4), "keyframes": int(sum(e["new_keyframe"] for e in log)),
+                "position_rmse_m": round(float(np.sqrt(np.mean(err ** 2))), 3), "distance_m": round(float(np.hypot(*np.diff(poses[:, :2], axis=0).T).sum()), 1)}
+
+
+def run_stream(args):
+    """BASELINE configs 3 / 4 as the reference runs them: ONE sequence (full_seq_1-like motion, unbounded reflector world with
+    movers, scintillation and, with motion distortion on, intra-scan distortion) through a 1-lane engine - frames from a pinned
+    ring on the copy stream, poses through the result ring.  (i) pipelined: steps enqueued as fast as the rings allow = engine-only
+    scan pairs/s of one sequence; (ii) latency: every pose awaited before the next frame is stepped."""
+    from radarslampy_amd import _ffi
+    n = args.stream_frames
+    md = not args.no_md
+    recs, poses = stream_render(args, md)
+    ctx = _ffi.Context(0)
+    info = ctx.device_info()
+    dt, cfg = stream_measure(recs, poses, md, ctx)
+    ctx.close()
     out = {"metric": "radar scan-pairs/sec (400x3768 polar), ONE sequence", "value": round((n - 1) / dt, 2), "unit": "scan-pairs/s",
            "n_gpus": 1, "steps": n - 1, "warmup": 11, "ms_per_step": round(dt / (n - 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8/f32/f64",
            "data": f"synthetic Oxford-format records along ground-truth motions {args.stream_start}..{args.stream_start + n - 2} of full_seq_1 (unbounded reflector world, 15 % movers, scintillation 0.4"
                    + (", intra-scan distortion)" if md else ")"),
-           "config": {"workload": "single-sequence streaming (BASELINE config " + ("4: motionDistortion ON" if md else "3: motionDistortion OFF")
-                                  + " + outlier rejection): 1 lane, frames uploaded from a pinned ring on the copy stream (host staging copy + PCIe included), every pose read back",
-                      "device": info["name"], "arch": info["arch"], "frames": n,
-                      "pipelined_pairs_per_s": round((n - 1) / dt, 2),
-                      "synchronous_pairs_per_s": round((n - 1) / dt2, 2),
-                      "latency_ms_per_pair": {"median": round(float(np.median(lat)), 3), "p95": round(float(np.percentile(lat, 95)), 3), "max": round(float(lat.max()), 3),
-                                              "median_steady_pair": round(float(np.median(lat[~rt])), 3) if (~rt).any() else None,
-                                              "median_retrack_pair": round(float(np.median(lat[rt])), 3) if rt.any() else None},
-                      "retrack_fraction": round(float(rt.mean()), 4), "keyframes": int(sum(e["new_keyframe"] for e in log)),
-                      "position_rmse_m": round(float(np.sqrt(np.mean(err ** 2))), 3), "distance_m": round(float(np.hypot(*np.diff(poses[:, :2], axis=0).T).sum()), 1)},
+           "config": dict({"workload": "single-sequence streaming (BASELINE config " + ("4: motionDistortion ON" if md else "3: motionDistortion OFF")
+                                       + " + outlier rejection): 1 lane, frames uploaded from a pinned ring on the copy stream (host staging copy + PCIe included), every pose read back",
+                           "device": info["name"], "arch": info["arch"]}, **cfg),
            "roofline": None, "cpu_baseline": None}
     print(json.dumps(out), flush=True)
 

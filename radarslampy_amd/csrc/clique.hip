@@ -75,20 +75,47 @@ __device__ __forceinline__ int wave_sum_i(int v)
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
-__device__ __forceinline__ int wave_min_i(int v)
+// wave-wide maximum / minimum of an int through the DPP network (row shifts, then the two row broadcasts of gfx9): six VALU
+// instructions instead of six ds_bpermute round trips; the result is wave-uniform (read back from lane 63)
+__device__ __forceinline__ int wave_max_i(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
-    return v;
+#define CQ_DPP_MAX(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false))
+    CQ_DPP_MAX(0x111, 0xf);     // row_shr:1
+    CQ_DPP_MAX(0x112, 0xf);     // row_shr:2
+    CQ_DPP_MAX(0x114, 0xf);     // row_shr:4
+    CQ_DPP_MAX(0x118, 0xf);     // row_shr:8   -> lane 15 of every row holds the row's maximum
+    CQ_DPP_MAX(0x142, 0xa);     // row_bcast:15 -> rows 1 and 3
+    CQ_DPP_MAX(0x143, 0xc);     // row_bcast:31 -> rows 2 and 3
+#undef CQ_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int bs_count(uint64_t x) { return wave_sum_i(__popcll(x)); }
-__device__ __forceinline__ int bs_first(uint64_t x)
+__device__ __forceinline__ int wave_min_i(int v) { return -wave_max_i(-v); }
+// A bitset lives in the first nw <= 16 lanes (one 64-bit word each), so its reductions are SCALAR work: the words that are not zero
+// (one ballot) are fetched with v_readlane and counted / searched on the scalar unit.  (The butterfly of six ds_bpermute exchanges
+// these replaced took ~700 cycles per call; the walk and the solver call them a dozen times per node.)
+__device__ __forceinline__ uint64_t bs_word(uint64_t x, int w)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(x & 0xffffffffull), w);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(x >> 32), w);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int bs_count(uint64_t x)
 {
     uint64_t bal = __ballot(x != 0);
+    int s = 0;
+    while (bal) {
+        const int w = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        s += __popcll(bs_word(x, w));
+    }
+    return s;
+}
+__device__ __forceinline__ int bs_first(uint64_t x)
+{
+    const uint64_t bal = __ballot(x != 0);
     if (!bal) return -1;
-    int fl = __ffsll((long long)bal) - 1;
-    uint64_t wv = shfl64(x, fl);
-    return fl * 64 + (__ffsll((long long)wv) - 1);
+    const int fl = __ffsll((long long)bal) - 1;
+    return fl * 64 + (__ffsll((long long)bs_word(x, fl)) - 1);
 }
 __device__ __forceinline__ uint64_t bit_if(int lane, int v) { return (lane == (v >> 6)) ? (1ull << (v & 63)) : 0ull; }
 
@@ -114,6 +141,9 @@ struct CqCtx {
     short *lsize, *lv, *lstage; // per level: |R|, branching vertex, stage
     long long nodes, node_limit;
     bool complete;
+#ifdef NX_EXP_STATS
+    int nq; long long nodes1;
+#endif
 };
 
 __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &REC)
@@ -240,7 +270,7 @@ struct NxSet {
     int mask, used;
     bool ident;
 };
-struct NxLds { uint16_t *tab[6], *seq, *seq2; int ts; };
+struct NxLds { uint16_t *tab[6], *seq, *seq2, *seq3, *slot; uint32_t *T; int ts; };
 
 __host__ __device__ inline int nx_table_slots(int K)
 {
@@ -250,7 +280,7 @@ __host__ __device__ inline int nx_table_slots(int K)
 }
 __host__ __device__ inline size_t nx_lds_bytes(int K)
 {
-    return (((size_t)6 * nx_table_slots(K) + 2 * (size_t)(K + 2)) * sizeof(uint16_t) + 15) & ~(size_t)15;
+    return (((size_t)6 * nx_table_slots(K) + 4 * (size_t)(K + 2)) * sizeof(uint16_t) + (size_t)nx_table_slots(K) * sizeof(uint32_t) + 15) & ~(size_t)15;
 }
 
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int src)
@@ -265,29 +295,13 @@ __device__ __forceinline__ int bs_last(uint64_t x)
     const uint64_t bal = __ballot(x != 0);
     if (!bal) return -1;
     const int hl = 63 - __clzll((long long)bal);
-    const uint64_t wv = rl64(x, hl);
+    const uint64_t wv = bs_word(x, hl);
     return hl * 64 + 63 - __clzll((long long)wv);
 }
 __device__ __forceinline__ uint64_t bits_from(int lane, int first)      // keys / slots >= first
 {
     const int w = first >> 6;
     return lane > w ? ~0ull : (lane == w ? (~0ull << (first & 63)) : 0ull);
-}
-
-// slot an insertion of `key` takes in a table with occupancy `occ` (set_add_entry / set_insert_clean without dummies)
-__device__ __forceinline__ int nx_probe(uint64_t occ, int mask, int key)
-{
-    unsigned perturb = (unsigned)key, i = (unsigned)key & (unsigned)mask;
-    for (;;) {
-        const int lim = (i + 9 <= (unsigned)mask) ? 9 : 0;
-        const int w0 = (int)(i >> 6), sh = (int)(i & 63);
-        uint64_t win = rl64(occ, w0) >> sh;
-        if (sh + lim >= 64) win |= rl64(occ, w0 + 1) << (64 - sh);
-        const uint64_t fr = ~win & ((2ull << lim) - 1ull);
-        if (fr) return (int)i + __ffsll((long long)fr) - 1;
-        perturb >>= 5;
-        i = (i * 5 + 1 + perturb) & (unsigned)mask;
-    }
 }
 
 // members of S that are in F, in S's iteration order -> seq[0..n); maxkey = the largest of them
@@ -324,9 +338,127 @@ __device__ int nx_seq(const CqCtx &c, const NxSet &S, uint64_t F, uint16_t *seq,
     return n;
 }
 
-// table of a set built by inserting seq[0..n) one by one (copy = false: growth 8 -> 32 -> 128 -> 512 -> 2048 as
-// set_add_entry resizes to used*4 once fill*5 >= mask*3) or in one go into the copy's table (copy = true: set_merge)
-__device__ void nx_build(const CqCtx &c, NxSet &D, const uint16_t *seq, int n, int maxkey, bool copy, uint16_t *tab, uint16_t *seq2)
+// slots the keys P[0..m) take when they are inserted IN THIS ORDER into an empty table of mask + 1 slots (set_insert_clean /
+// set_add_entry without dummies; the keys are distinct).  Sequentially that is a chain of m dependent probes; here every key
+// (a lane each) walks its probe sequence against T[s] = the EARLIEST key currently assigned to slot s and takes the first slot no
+// earlier key holds; T is rebuilt and the walk repeated until nothing moves.  A key's choice depends on earlier keys only, so after
+// k rounds the first k keys sit where the sequential insertion puts them, and the fixed point is the sequential result; the rounds
+// needed are the longest chain of displacements (a handful at the load factors CPython allows), not m.  Returns the occupancy.
+__device__ uint64_t nx_phase(const CqCtx &c, const uint16_t *P, int m, int mask, uint16_t *slot, uint32_t *T)
+{
+    const int lane = c.lane;
+    for (int i = lane; i < m; i += 64) slot[i] = (uint16_t)(P[i] & mask);
+    for (;;) {
+        __syncthreads();
+        for (int s0 = lane; s0 <= mask; s0 += 64) T[s0] = 0xffffffffu;
+        __syncthreads();
+        // (atomicMin through a generic pointer to LDS raises a memory-aperture fault here: the minimum by repeated plain stores)
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            for (;;) {
+                const bool want = i < m && T[slot[i]] > (uint32_t)i;
+                if (!__ballot(want)) break;
+                if (want) T[slot[i]] = (uint32_t)i;
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        bool moved = false;
+        for (int i = lane; i < m; i += 64) {
+            const unsigned key = P[i];
+            unsigned perturb = key, i0 = key & (unsigned)mask, got;
+            for (;;) {
+                const int lim = (i0 + 9 <= (unsigned)mask) ? 9 : 0;
+                int j = 0;
+                for (; j <= lim; j++) if (T[i0 + j] >= (uint32_t)i) break;
+                if (j <= lim) { got = i0 + j; break; }
+                perturb >>= 5;
+                i0 = (i0 * 5 + 1 + perturb) & (unsigned)mask;
+            }
+            if (got != slot[i]) { moved = true; slot[i] = (uint16_t)got; }
+        }
+        if (!__ballot(moved)) break;
+    }
+    uint64_t occ = 0;
+    for (int ch = 0; ch * 64 <= mask; ch++) {
+        const uint64_t b = __ballot(ch * 64 + lane <= mask && T[ch * 64 + lane] != 0xffffffffu);
+        if (lane == ch) occ = b;
+    }
+    return occ;
+}
+
+// P2[0..m) = the keys P[0..m) in the order of their slots (what set_table_resize re-inserts, what iteration yields)
+__device__ void nx_slot_order(const CqCtx &c, const uint16_t *P, const uint16_t *slot, int m, uint64_t occ, uint16_t *P2)
+{
+    const int lane = c.lane;
+    __syncthreads();
+    if (lane < 16) c.sw[lane] = occ;                                   // tables of at most 1024 slots reach this point
+    __syncthreads();
+    for (int i = lane; i < m; i += 64) {
+        const int sl = slot[i], w = sl >> 6;
+        int r = __popcll(c.sw[w] & ((1ull << (sl & 63)) - 1ull));
+        for (int k = 0; k < w; k++) r += __popcll(c.sw[k]);
+        P2[r] = P[i];
+    }
+    __syncthreads();
+}
+
+// slot of `key` in a table of at most 128 slots whose occupancy is the pair (o0, o1): everything wave-uniform, scalar ALU only
+__device__ __forceinline__ int nx_probe2(uint64_t o0, uint64_t o1, int mask, int key)
+{
+    unsigned perturb = (unsigned)key, i = (unsigned)key & (unsigned)mask;
+    for (;;) {
+        const int lim = (i + 9 <= (unsigned)mask) ? 9 : 0;
+        const int sh = (int)(i & 63);
+        uint64_t win = ((i >> 6) ? o1 : o0) >> sh;
+        if (sh + lim >= 64) win |= o1 << (64 - sh);                   // (i < 64 here: i + 9 <= mask <= 127)
+        const uint64_t fr = ~win & ((2ull << lim) - 1ull);
+        if (fr) return (int)i + __ffsll((long long)fr) - 1;
+        perturb >>= 5;
+        i = (i * 5 + 1 + perturb) & (unsigned)mask;
+    }
+}
+
+// nx_build for sets of at most 64 members in tables of at most 128 slots (every explicit table but a few when K <= 512): the keys sit
+// in ONE register (lane j = the j-th key inserted), an insertion is v_readlane + a dozen scalar instructions + a lane select for the
+// slot, and "re-insert in slot order" at a resize is one ds_permute by the rank of the slot.  Kept out of line: inlined into the walk
+// (three copies of the loop) the kernel needed 199 registers and the build of ROCm 7.2 produced a binary that faulted.
+// one pass: keys of lanes 0..m-1 into an empty table; the lane's slot lands in sv, the occupancy in (o0, o1)
+__device__ __forceinline__ void nx_run_small(int lane, int kv, int &sv, uint64_t &o0, uint64_t &o1, int m, int mask)
+{
+    o0 = 0; o1 = 0;
+    for (int j = 0; j < m; j++) {
+        const int key = __builtin_amdgcn_readlane(kv, j);
+        int sl = key & mask;
+        if ((((sl >> 6) ? o1 : o0) >> (sl & 63)) & 1ull) sl = nx_probe2(o0, o1, mask, key);      // (home slot taken: the probe sequence)
+        if (sl < 64) o0 |= 1ull << sl; else o1 |= 1ull << (sl - 64);
+        sv = lane == j ? sl : sv;
+    }
+}
+__device__ __forceinline__ int nx_reorder_small(int lane, int kv, int sv, uint64_t o0, int m)
+{
+    const int r = __popcll(o0 & ((1ull << (sv & 63)) - 1ull));       // (a table of <= 32 slots) rank of the lane's slot
+    return __builtin_amdgcn_ds_permute((lane < m ? r : lane) << 2, kv);
+}
+__device__ __attribute__((noinline)) void nx_build_small(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab)
+{
+    // (arguments of an out-of-line function arrive in vector registers: say that these are wave-uniform, or every loop below
+    // becomes a divergent one and v_readlane a waterfall)
+    const int n = __builtin_amdgcn_readfirstlane(n_), size = __builtin_amdgcn_readfirstlane(size_);
+    const bool copy = __builtin_amdgcn_readfirstlane((int)copy_) != 0;
+    int kv = lane < n ? (int)seq[lane] : 0, sv = 0;
+    uint64_t o0 = 0, o1 = 0;
+    // the tables the set goes through: 5 keys in 8 slots, 19 in 32, then all of them in the final one
+    if (!copy && n >= 5 && size > 8) { nx_run_small(lane, kv, sv, o0, o1, 5, 7); kv = nx_reorder_small(lane, kv, sv, o0, 5); }
+    if (!copy && n >= 19 && size > 32) { nx_run_small(lane, kv, sv, o0, o1, 19, 31); kv = nx_reorder_small(lane, kv, sv, o0, 19); }
+    nx_run_small(lane, kv, sv, o0, o1, n, size - 1);
+    if (lane < n) tab[sv] = (uint16_t)kv;
+    *occ_out = lane == 0 ? o0 : (lane == 1 ? o1 : 0ull);
+}
+
+// table of a set built by inserting seq[0..n) one by one (copy = false: growth 8 -> 32 -> 128 -> 512 -> 2048, set_add_entry
+// resizing to used*4 once fill*5 >= mask*3 and re-inserting in slot order) or in one go into the copy's table (copy = true)
+__device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq, int n, int maxkey, bool copy, uint16_t *tab)
 {
     const int lane = c.lane;
     int size = 8;
@@ -334,57 +466,60 @@ __device__ void nx_build(const CqCtx &c, NxSet &D, const uint16_t *seq, int n, i
     else size = n < 5 ? 8 : n < 19 ? 32 : n < 77 ? 128 : n < 307 ? 512 : 2048;
     D.used = n; D.tab = tab; D.occ = 0; D.mask = size - 1;
     D.ident = maxkey < size;
+#ifdef NX_EXP_NOBUILD
+    D.ident = true;
+#endif
     if (D.ident) return;
-    const uint64_t below = (1ull << lane) - 1ull;
-    int mask = copy ? size - 1 : 7, fill = 0;
-    uint64_t occ = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int kv = (i0 + lane < n) ? (int)seq[i0 + lane] : 0;
-        const int m = min(64, n - i0);
-        for (int j = 0; j < m; j++) {
-            const int key = __builtin_amdgcn_readlane(kv, j);
-            const int slot = nx_probe(occ, mask, key);
-            if (lane == 0) tab[slot] = (uint16_t)key;
-            if (lane == (slot >> 6)) occ |= 1ull << (slot & 63);
-            fill++;
-            if (!copy && fill * 5 >= mask * 3) {                        // set_table_resize(used * 4): re-insert in slot order
-                int ns = 8;
-                while (ns <= fill * 4) ns <<= 1;
-                __syncthreads();
-                int cnt = 0;
-                for (int ch = 0; ch * 64 <= mask; ch++) {
-                    const uint64_t ob = rl64(occ, ch);
-                    if (!ob) continue;
-                    if ((ob >> lane) & 1ull) seq2[cnt + __popcll(ob & below)] = tab[ch * 64 + lane];
-                    cnt += __popcll(ob);
-                }
-                __syncthreads();
-                occ = 0; mask = ns - 1;
-                for (int r0 = 0; r0 < cnt; r0 += 64) {
-                    const int rv = (r0 + lane < cnt) ? (int)seq2[r0 + lane] : 0;
-                    const int rm = min(64, cnt - r0);
-                    for (int r = 0; r < rm; r++) {
-                        const int k2 = __builtin_amdgcn_readlane(rv, r);
-                        const int s2 = nx_probe(occ, mask, k2);
-                        if (lane == 0) tab[s2] = (uint16_t)k2;
-                        if (lane == (s2 >> 6)) occ |= 1ull << (s2 & 63);
-                    }
-                }
-                __syncthreads();
-            }
+    if (size <= 128 && n <= 64) {
+        uint64_t o;
+        nx_build_small(c.lane, &o, seq, n, size, copy, tab);
+        __syncthreads();
+        D.occ = o;
+        return;
+    }
+    const uint16_t *P = seq;
+    uint16_t *bufa = L.seq2, *bufb = L.seq3;
+    if (!copy) {
+        // the tables the set went through before its last resize: 5 keys in 8 slots, 19 in 32, 77 in 128
+        const int cut[3] = {5, 19, 77}, msk[3] = {7, 31, 127};
+        int have = 0;                                                   // P[0..have) = the re-inserted keys, then seq[have..)
+        for (int ph = 0; ph < 3 && n >= cut[ph] && msk[ph] < size - 1; ph++) {
+            const int m = cut[ph];
+            // list of this phase: the previous phase's keys in slot order + the keys inserted since
+            uint16_t *cur = (P == bufa) ? bufb : bufa;
+            for (int i = lane; i < m; i += 64) cur[i] = (i < have) ? P[i] : seq[i];
+            __syncthreads();
+            const uint64_t occ = nx_phase(c, cur, m, msk[ph], L.slot, L.T);
+            uint16_t *nxt = (cur == bufa) ? bufb : bufa;
+            nx_slot_order(c, cur, L.slot, m, occ, nxt);
+            P = nxt; have = m;
+        }
+        if (have) {
+            uint16_t *cur = (P == bufa) ? bufb : bufa;
+            for (int i = lane; i < n; i += 64) cur[i] = (i < have) ? P[i] : seq[i];
+            __syncthreads();
+            P = cur;
         }
     }
+    const uint64_t occ = nx_phase(c, P, n, size - 1, L.slot, L.T);
+    for (int i = lane; i < n; i += 64) tab[L.slot[i]] = P[i];
     __syncthreads();
-    D.occ = occ; D.mask = mask;
+    D.occ = occ;
 }
+
+__device__ __forceinline__ int nx_incr_size(int n) { return n < 5 ? 8 : n < 19 ? 32 : n < 77 ? 128 : n < 307 ? 512 : 2048; }
 
 // D = {x in ITER's order if x in F}: set_intersection / the iterating branch of set_difference
 __device__ void nx_filter_build(const CqCtx &c, NxLds &L, NxSet &D, const NxSet &ITER, uint64_t F, uint16_t *tab)
 {
+    const uint64_t X = ITER.live & F;
+    D.live = X;
+    // the common case needs no replay at all: every key below the table size => each key in its own slot, whatever the order
+    const int n0 = bs_count(X), mk0 = bs_last(X);
+    if (mk0 < nx_incr_size(n0)) { D.used = n0; D.tab = tab; D.occ = 0; D.mask = nx_incr_size(n0) - 1; D.ident = true; return; }
     int maxkey;
     const int n = nx_seq(c, ITER, F, L.seq, maxkey);
-    D.live = ITER.live & F;
-    nx_build(c, D, L.seq, n, maxkey, false, tab, L.seq2);
+    nx_build(c, L, D, L.seq, n, maxkey, false, tab);
 }
 
 // adj[q] = {v for v in G[q] if v != q}: ascending insertion of the row
@@ -424,13 +559,11 @@ __device__ int nx_pivot(const CqCtx &c, const NxSet &SG, uint64_t candbits)
         const int key = (d << 12) | (4095 - pos);
         if (key > best) { best = key; bestu = u; }
     }
-    int m = best;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    const int m = wave_max_i(best);
     const uint64_t who = __ballot(best == m);
     const int src = __ffsll((long long)who) - 1;
     __syncthreads();
-    return __shfl(bestu, src);
+    return __builtin_amdgcn_readlane(bestu, src);
 }
 
 // ext_u = cand - adj[u]
@@ -447,7 +580,7 @@ __device__ void nx_sub_adj(const CqCtx &c, NxLds &L, NxSet &E, const NxSet &CD, 
             int maxkey;
             const int n = nx_seq(c, CD, ~0ull, L.seq, maxkey);
             E.live = CD.live;
-            nx_build(c, E, L.seq, n, maxkey, true, L.tab[5], L.seq2);
+            nx_build(c, L, E, L.seq, n, maxkey, true, L.tab[5]);
         }
         E.live &= ~row;                                                 // discards leave dummies: the layout stays
         E.used = bs_count(E.live);
@@ -480,27 +613,69 @@ __device__ int nx_pop(const CqCtx &c, NxSet &E)
     return q;
 }
 
+// ext_u of at most four members out of an ascending cand (by far the commonest case: the pivot is adjacent to almost everything): the
+// 8-slot table is replayed on the scalar unit and the members come back packed in pop order, 16 bits each.  false: not this case.
+__device__ __forceinline__ bool nx_sub_adj_tiny(const CqCtx &c, const NxSet &CD, uint64_t row, int deg, uint64_t &elist, int &en)
+{
+    if (!CD.ident || (CD.used >> 2) > deg) return false;
+    uint64_t X = CD.live & ~row;
+    const int n = bs_count(X);
+    if (n > 4) return false;
+    unsigned occ = 0;
+    unsigned e0 = ~0u, e1 = ~0u, e2 = ~0u, e3 = ~0u;                   // (slot << 16) | key; unused entries sort to the end
+#define NX_TINY_INS(e, k)                                                                                               \
+    if (k < n) {                                                                                                        \
+        const int key = bs_first(X);                                                                                    \
+        X &= ~bit_if(c.lane, key);                                                                                      \
+        unsigned perturb = (unsigned)key, i = (unsigned)key & 7u;                                                       \
+        while ((occ >> i) & 1u) { perturb >>= 5; i = (i * 5 + 1 + perturb) & 7u; }     /* mask 7: no linear probes */     \
+        occ |= 1u << i;                                                                                                 \
+        e = (i << 16) | (unsigned)key;                                                                                  \
+    }
+    NX_TINY_INS(e0, 0) NX_TINY_INS(e1, 1) NX_TINY_INS(e2, 2) NX_TINY_INS(e3, 3)
+#undef NX_TINY_INS
+#define NX_CSWAP(a, b) { const unsigned lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+    NX_CSWAP(e0, e1) NX_CSWAP(e2, e3) NX_CSWAP(e0, e2) NX_CSWAP(e1, e3) NX_CSWAP(e1, e2)
+#undef NX_CSWAP
+    elist = (uint64_t)(e0 & 0xffffu) | ((uint64_t)(e1 & 0xffffu) << 16) | ((uint64_t)(e2 & 0xffffu) << 32) | ((uint64_t)(e3 & 0xffffu) << 48);
+    en = n;
+    return true;
+}
+
 // RF = the first clique of size omega in networkx.find_cliques order.  false: the bounded searches ran out of nodes.
 __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uint64_t WIT, uint64_t &RF)
 {
     const int lane = c.lane, nw = c.nw;
     NxSet subg, cand, ext;
+    uint64_t elist = 0;                                                 // ext_u of <= 4 members: packed pop order (nx_sub_adj_tiny)
+    int en = -1;                                                        // ... its remaining count, -1 = ext is the set `ext`
     int cur = 0;
     cand.live = ALL; cand.ident = true; cand.used = Kb; cand.occ = 0; cand.tab = L.tab[2];                     // set(G): every key < table size
     cand.mask = (Kb < 5 ? 8 : Kb < 19 ? 32 : Kb < 77 ? 128 : Kb < 307 ? 512 : 2048) - 1;
     subg = cand; subg.tab = L.tab[0];                                                                          // cand.copy(): likewise
-    {
-        const int pu = nx_pivot(c, subg, cand.live);
-        const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
-        nx_sub_adj(c, L, ext, cand, prow, bs_count(prow));
-    }
     RF = 0;
     int size = 0;
+    bool entered = true;                                                // a node was just entered: its pivot and ext_u are due
+    // (every helper appears ONCE in this loop: with the set-up of a node written out before the loop as well, the kernel grew past
+    // what this compiler turns into a working binary - the build faulted in code that never ran)
+#pragma nounroll
     for (;;) {
-        const int q = nx_pop(c, ext);
+        if (entered) {
+            entered = false;
+            const int pu = nx_pivot(c, subg, cand.live);
+            const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
+            const int pdeg = bs_count(prow);
+            if (!nx_sub_adj_tiny(c, cand, prow, pdeg, elist, en)) { en = -1; nx_sub_adj(c, L, ext, cand, prow, pdeg); }
+        }
+        int q;
+        if (en >= 0) {
+            q = en ? (int)(elist & 0xffffull) : -1;
+            elist >>= 16; en--;
+        } else
+            q = nx_pop(c, ext);
         if (q < 0) return false;                                        // cannot happen while the existence answers are exact
         const uint64_t bq = bit_if(lane, q);
-        if (cand.live & bq) { cand.live &= ~bq; }                       // cand.remove(q): a dummy stays in its slot
+        cand.live &= ~bq;                                               // cand.remove(q): a dummy stays in its slot
         cand.used--;
         const uint64_t row = (lane < nw) ? c.A[(int64_t)q * c.as + lane] : 0ull;
         const uint64_t Sq = subg.live & row, Cq = cand.live & row;
@@ -518,21 +693,26 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
         bool ok = !__ballot((QB & ~WIT) != 0) && !__ballot((WIT & ~QB & ~Cq) != 0);      // the witness lives in this subtree
         if (!ok) {
             uint64_t RQ = 0;
+#ifdef NX_EXP_STATS
+            c.nq++;
+#endif
             const int got = cq_solve(c, Cq, need - 1, need, RQ);
             if (!c.complete) return false;
             if (got >= need) { ok = true; WIT = QB | RQ; }
         }
         if (!ok) continue;
-        // descend: subg_q = subg & adj[q], cand_q = cand & adj[q], the new pivot and ext_u
+        // descend: subg_q = subg & adj[q], cand_q = cand & adj[q]
         const int deg = bs_count(row);
         NxSet nsub, ncand;
-        nx_and_adj(c, L, nsub, subg, subg.used, row, deg, L.tab[cur ^ 1]);
-        nx_and_adj(c, L, ncand, cand, cand.used, row, deg, L.tab[2 + (cur ^ 1)]);
+#pragma nounroll
+        for (int which = 0; which < 2; which++) {
+            const NxSet &S = which ? cand : subg;
+            NxSet &D = which ? ncand : nsub;
+            nx_and_adj(c, L, D, S, S.used, row, deg, L.tab[2 * which + (cur ^ 1)]);
+        }
         subg = nsub; cand = ncand; cur ^= 1;
         RF = QB; size = s1;
-        const int pu = nx_pivot(c, subg, cand.live);
-        const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
-        nx_sub_adj(c, L, ext, cand, prow, bs_count(prow));
+        entered = true;
     }
 }
 
@@ -583,15 +763,25 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
     // ---- phase 1: omega and one maximum clique (the witness)
     uint64_t WIT = 0;
     const int omega = cq_solve(c, ALL, 0, 0x7fffffff, WIT);
+#ifdef NX_EXP_STATS
+    c.nq = 0; c.nodes1 = c.nodes;
+#endif
     // ---- phase 2: the first clique of size omega in networkx.find_cliques order (nx_walk)
     uint64_t REC = WIT;
+#ifdef NX_EXP_NOWALK
+    if (false) {
+#else
     if (c.complete && omega > 0) {
+#endif
         NxLds L;
         L.ts = nx_table_slots(K);
         uint16_t *base = reinterpret_cast<uint16_t *>(nx_mem);
         for (int t = 0; t < 6; t++) L.tab[t] = base + t * L.ts;
         L.seq = base + 6 * L.ts;
         L.seq2 = L.seq + (K + 2);
+        L.seq3 = L.seq2 + (K + 2);
+        L.slot = L.seq3 + (K + 2);
+        L.T = reinterpret_cast<uint32_t *>(L.slot + (K + 2) + ((6 * L.ts + 4 * (K + 2)) & 1));
         uint64_t RF = 0;
         if (nx_walk(c, L, Kb, ALL, omega, WIT, RF)) REC = RF;
     }
@@ -603,6 +793,10 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
     for (int u = Kb + lane; u < kstride && u < K; u += 64) mask[u] = 0;
     const int cnt = bs_count(REC);
     if (lane == 0) { n_in[b] = cnt; flags[b] = c.complete ? 1 : 0; }
+#ifdef NX_EXP_STATS
+    if (lane == 0) flags[b] |= (min(c.nq, 255) << 8) | ((int)min((c.nodes - c.nodes1), 32767ll) << 16);
+    if (lane == 0) n_in[b] = cnt | ((int)min(c.nodes1, 32767ll) << 16);
+#endif
 }
 
 // adj rows have stride nws words; stack scratch: B x (kstride+2) x 2 x nws words

@@ -1122,6 +1122,14 @@ int32_t roam_engine_step_results(roam_ctx *ctx, int64_t step, roam_lane_result *
     const int rs = (int)(step % RES_RING);
     HIP_TRY(ctx, hipEventSynchronize(e->ev_res[rs]));      // waits for that step's records only; later steps keep running
     memcpy(out, e->results_host + (size_t)rs * e->B, sizeof(roam_lane_result) * (size_t)n);
+    if (e->rt_on && e->rt_floor > 320 && step == e->nstep - 1 && e->rt_mode != 2) {
+        // a forced (mode 2) step inflated the launch width of every later KLT / graph launch; the records of the LATEST step say
+        // what every lane really holds, and lanes only shrink (or re-detect to <= 60 + 256) from here on
+        const roam_lane_result *r = e->results_host + (size_t)rs * e->B;
+        int m = 320;
+        for (int b = 0; b < e->B; b++) m = std::max(m, (int)((r[b].flags & 8) ? r[b].n_after_retrack : r[b].n_inliers));
+        e->rt_floor = std::min(e->rt_floor, (m + 63) & ~63);
+    }
     return ROAM_OK;
 }
 
@@ -1327,9 +1335,11 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             }
             HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, which));
             const double npx = (double)e->W * e->W;
-            // algorithmic bytes per detection: integral image (one sweep) = polar payload + 4-byte map word per pixel read, float64
-            // image written once; determinants + maxima = float64 image read once (the candidates it writes are a few KB)
-            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 4.0 + npx * 8.0) : npx * 8.0);
+            // algorithmic bytes per detection (strict): integral image = polar payload read + float64 image written once
+            // (the 4-byte sampling-map word per pixel it also reads is the same geometry table for every detection and mostly comes
+            // out of L2: not input data, not counted since round 4); determinants + maxima = float64 image read once (the
+            // candidates it writes are a few KB)
+            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 8.0) : npx * 8.0);
         } else if (!strcmp(name, "pyramid")) {
             HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B, e->pyr_dark));
             double rd = 0, wr = 0;

@@ -1325,11 +1325,13 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         hipEvent_t *tev = trace + 3 * (first / R);
         if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
         if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
+        if ((e = hipGetLastError()) != hipSuccess) return e;              // (a refused launch - LDS attribute, grid - surfaces here, not after the chain)
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, first);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
         if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[2], st)) != hipSuccess) return e;
