@@ -533,6 +533,14 @@ __device__ void nx_adj_set(const CqCtx &c, NxLds &L, NxSet &D, uint64_t row, uin
 __device__ void nx_and_adj(const CqCtx &c, NxLds &L, NxSet &D, const NxSet &S, int slen, uint64_t row, int deg, uint16_t *tab)
 {
     if (deg > slen) { nx_filter_build(c, L, D, S, row, tab); return; }
+    // adj[q] is the iterated operand.  It was built by ascending insertion: when all its keys are below its table size it iterates
+    // in ascending order, and so does the result's insertion sequence - no table of adj[q] is needed (nearly always: 77+ neighbours
+    // sit in 512 slots)
+    if (bs_last(row) < nx_incr_size(deg)) {
+        NxSet asc; asc.live = row; asc.ident = true; asc.mask = 0; asc.used = deg; asc.occ = 0; asc.tab = nullptr;
+        nx_filter_build(c, L, D, asc, S.live, tab);
+        return;
+    }
     NxSet A;
     nx_adj_set(c, L, A, row, L.tab[4]);
     nx_filter_build(c, L, D, A, S.live, tab);
