@@ -57,6 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--h2d", action="store_true", help="stream every scan from pinned host memory over PCIe (double-buffered pool); reports the PCIe-inclusive rate")
     ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
     ap.add_argument("--force-comm", action="store_true", help="create the RCCL communicator even at world size 1 (exercises the collective path on a 1-GPU box)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5: ONE sequence per rank (seed 10 + rank) through a 1-lane streaming engine, "
+                    "the keyframe exchange (roam_keyframe_exchange: one RCCL all-gather of fixed-size records) after EVERY step inside the loop, every rank "
+                    "appending what it receives to its device-resident global map")
+    ap.add_argument("--c5-frames", type=int, default=1000, help="scans per sequence of --config5")
     ap.add_argument("--no-segments", action="store_true", help="skip the extra segments of the default run (endless ping-pong steps, single-sequence streaming)")
     ap.add_argument("--dry-engine", action="store_true", help="CPU stub instead of the GPU engine: exercises launcher / rendezvous / reduction only")
     args = ap.parse_args(argv)
@@ -828,6 +832,126 @@ def run_stream(args):
     print(json.dumps(out), flush=True)
 
 
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5
+class DryStreamEngine:
+    """CPU stand-in of the 1-lane streaming engine + its keyframe exchange (launcher / schedule test only)"""
+
+    def __init__(self, rank, comm):
+        self.rank, self.comm, self.n, self.map, self.sent = rank, comm, 0, [], 0
+
+    def step(self):
+        self.n += 1
+        time.sleep(0.0005)
+
+    def keyframe_exchange(self, lane=0):
+        mine = (self.n * 7 + self.rank * 3) % 5 == 0                      # "this step made a keyframe", rank- and step-dependent
+        self.sent += mine
+        got = self.comm.rdv.gather(f"kfx{self.n}", json.dumps(dict(valid=bool(mine), root=self.rank, step=self.n)).encode())
+        self.map += [json.loads(g) for g in got if json.loads(g)["valid"]]
+
+
+def run_config5(args):
+    """one process per GPU, one sequence per rank; after EACH step every rank contributes its new keyframe (or an empty record) to
+    one all-gather and appends what it receives to its remote map - inside the loop, without draining the step pipeline"""
+    from radarslampy_amd import distributed as D
+    rank, local_rank, world = D.rank_env()
+    rdv = D.FileRendezvous(D.rendezvous_dir(), rank, world)
+    if world > 1:
+        rdv.watchdog()
+    n = args.c5_frames
+    md = not args.no_md
+    try:
+        if args.dry_engine:
+            comm = D.FileComm(rdv)
+            eng = DryStreamEngine(rank, comm)
+            comm.barrier()
+            t0 = time.perf_counter()
+            for k in range(1, n):
+                eng.step()
+                eng.keyframe_exchange(0)
+            comm.barrier()
+            dt = comm.allreduce_max(time.perf_counter() - t0)
+            sent = [int(x) for x in rdv.gather("sent", str(eng.sent).encode())]
+            out = dict(map_received=len(eng.map), keyframes_sent_per_rank=sent, senders=sorted({m["root"] for m in eng.map}),
+                       backend=comm.backend, us_per_exchange=None, pairs_per_s_without_exchange=None, device="dry", arch="none")
+            assert len(eng.map) == sum(sent), (len(eng.map), sent)
+            comm.close()
+        else:
+            from radarslampy_amd import _ffi, synth
+            from radarslampy_amd.RawROAMSystem import stream_records
+            gold = os.path.join(ROOT, "tests", "golden", "full_seq_1_gt_deltas.npz")
+            start = args.stream_start + 97 * rank                        # every rank drives its own stretch of full_seq_1's motions
+            deltas = np.load(gold)["deltas"][start:start + n - 1]
+            poses = synth.poses_from_deltas(deltas)
+            jobs = synth.stream_jobs(synth.StreamWorld(10 + rank, mover_fraction=0.15), poses, distortion=md, scintillation=0.4)
+            import multiprocessing as mp
+            pool = mp.get_context("spawn").Pool(max(1, min(48, (os.cpu_count() or 2) // (2 * world))))
+            try:
+                recs = pool.map(synth._render_job, jobs, chunksize=4)
+                pool.close(); pool.join()
+            except BaseException:
+                pool.terminate()
+                raise
+            ctx = _ffi.Context(local_rank)
+            info = ctx.device_info()
+            votes = rdv.gather("rccl_available", b"1" if D.RcclComm.available(ctx) else b"0")
+            if not all(v == b"1" for v in votes):
+                raise RuntimeError("config 5 needs RCCL on every rank")
+            comm = D.RcclComm(ctx, rdv)
+            flags = {"rejectOutliers": True, "correctMotionDistortion": md}
+            stream_records(iter(recs[:12]), 12, poses[0], flags, ctx)                       # warm-up (allocations, first launches)
+            state = {}
+
+            def on_engine(eng):
+                eng.remote_map_reserve(4096)
+
+            def after_step(eng, k):
+                eng.keyframe_exchange(0)
+
+            def before_close(eng):
+                state["map"] = eng.remote_map_count()
+                state["last"] = eng.remote_map_get(state["map"][1] - 1) if state["map"][1] else None
+            # without the exchange first (= --stream), then with it, both between barriers
+            comm.barrier()
+            t0 = time.perf_counter()
+            est0, log0 = stream_records(iter(recs), n, poses[0], flags, ctx)
+            dt0 = comm.allreduce_max(time.perf_counter() - t0)
+            comm.barrier()
+            t0 = time.perf_counter()
+            est, log = stream_records(iter(recs), n, poses[0], flags, ctx, on_engine=on_engine, after_step=after_step, before_close=before_close)
+            dt = comm.allreduce_max(time.perf_counter() - t0)
+            assert est.tobytes() == est0.tobytes()                                          # the exchange does not touch the odometry
+            mine = int(sum(e["new_keyframe"] for e in log))
+            sent = [int(x) for x in rdv.gather("sent", str(mine).encode())]
+            n_rec, n_res = state["map"]
+            assert n_rec == sum(sent), (n_rec, sent)                                        # every keyframe of every rank arrived, once
+            last = state["last"]
+            assert last is None or (last["prunedUndistortedLocals"].shape[1] == 2 and 0 <= last["root"] < world)
+            out = dict(map_received=int(n_rec), keyframes_sent_per_rank=sent, senders=sorted({ctx_r for ctx_r in range(world) if sent[ctx_r]}),
+                       backend=comm.backend, us_per_exchange=round((dt - dt0) / (n - 1) * 1e6, 2),
+                       pairs_per_s_without_exchange=round(world * (n - 1) / dt0, 2), device=info["name"], arch=info["arch"],
+                       comm_rank_world_seen=comm.info(), retrack_fraction=round(float(np.mean([e["retrack"] for e in log])), 4))
+            comm.close()
+            ctx.close()
+    except BaseException as ex:                          # noqa: BLE001
+        rdv.mark_failed(repr(ex))
+        raise
+    if rank == 0:
+        line = {"metric": "radar scan-pairs/sec (400x3768 polar), one sequence per GPU + keyframe exchange", "value": round(world * (n - 1) / dt, 2),
+                "unit": "scan-pairs/s", "n_gpus": world, "steps": n - 1, "warmup": 11, "ms_per_step": round(dt / (n - 1) * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
+                "data": f"synthetic Oxford-format records, one sequence of {n} scans per rank (reflector world seed 10 + rank, 15 % movers, scintillation 0.4, "
+                        "its own stretch of full_seq_1's ground-truth motions)",
+                "config": dict({"workload": "BASELINE config 5: one sequence per GPU through a 1-lane streaming engine (pinned ring, result ring); after EVERY step "
+                                            "each rank puts its new keyframe {pose, velocity, undistorted features, <= 32768 polar peaks} or an empty record into ONE "
+                                            "ncclAllGather of fixed-size records on the exchange stream and appends every non-empty record to its device-resident "
+                                            "global map (Mapping.Map.addKeyframe on every rank); no host synchronisation inside the loop",
+                                "frames": n, "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("bench.py --gpus" if world > 1 else "single process")}, **out),
+                "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -836,6 +960,9 @@ def main():
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, argv))
+    if args.config5:
+        run_config5(args)
+        return
     run_rank(args)
 
 

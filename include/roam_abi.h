@@ -328,6 +328,16 @@ typedef struct roam_keyframe_hdr {
 int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyframe_hdr *hdr_out, double *locals_xy,
                             int32_t cap_pts, int32_t *peaks, int64_t peaks_cap);
 
+/* BASELINE config 5 as a loop (reference RawROAMSystem.py:250-262 + Mapping.Map.addKeyframe, Mapping.py:176-180: "after each
+ * keyframe the owning GPU broadcasts"): collective and NON-BLOCKING, called by every rank once after each roam_engine_step with
+ * its own lane.  Which rank has a new keyframe in a given step is only known on that rank's device, so the schedule is fixed: every
+ * rank contributes ONE fixed-size record per step - its lane's new keyframe {header, prunedUndistortedLocals, up to 32768 polar
+ * peaks} if the step made one (result flag bit 1), an empty record otherwise - to one ncclAllGather on the engine's exchange
+ * stream, and appends every non-empty record it receives to its remote map on the device, in rank order.  Nothing waits on the host
+ * and the step pipeline is not drained; roam_remote_map_count / _get wait for the exchange stream.  Needs roam_comm_init and
+ * roam_remote_map_reserve; do not mix with roam_bcast_keyframe on one engine. */
+int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane);
+
 /* The consumer of that broadcast: Map.addKeyframe (Mapping.py:118-147) on EVERY rank.  After roam_remote_map_reserve(n) each
  * roam_bcast_keyframe also appends the received payload {header, prunedUndistortedLocals, polar peaks} device-to-device to a
  * ring of n keyframes in this rank's HBM (the oldest is overwritten); the sending rank included, so all ranks hold the same

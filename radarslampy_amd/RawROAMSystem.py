@@ -67,17 +67,21 @@ class RawROAMSystem:
 
 
 def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows=400, stride=3779, payload_off=11, clip=2025,
-                   synchronous=False):
+                   synchronous=False, on_engine=None, after_step=None, before_close=None):
     """records: iterator of n_frames (rows, stride) u8 Oxford records of ONE sequence.  -> (poses (n_frames-1, 3), per-pair log).
     Frame 0 seeds the lane (features detected on the device); frame k is uploaded LOOKAHEAD frames before step k needs it.
     synchronous=True awaits every pose before the next frame is stepped (the latency of one pair instead of the pipeline's
-    rate; same poses) and also returns the per-pair seconds from the step call to the pose on the host."""
+    rate; same poses) and also returns the per-pair seconds from the step call to the pose on the host.
+    Hooks (the multi-GPU keyframe exchange of BASELINE config 5 lives in them): on_engine(eng) once after the engine exists,
+    after_step(eng, k) after every enqueued step, before_close(eng) when all poses are in."""
     flags = dict(paramFlags or {})
     own = ctx is None
     ctx = ctx or _ffi.Context(int(os.environ.get("ROAM_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     eng = Engine(1, RING, ctx=ctx, rows=rows, stride=stride, payload_off=payload_off, clip=clip,
                  reject_outliers=flags.get("rejectOutliers", True), motion_distortion=flags.get("correctMotionDistortion", True),
                  retrack_on_device=True)
+    if on_engine is not None:
+        on_engine(eng)
     pinned = ctx.host_alloc((RING, rows, stride))
     it = iter(records)
     uploaded = 0
@@ -113,6 +117,8 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
                 import time
                 t0 = time.perf_counter()
             eng.step([k % RING])
+            if after_step is not None:
+                after_step(eng, k)
             # slot (k + LOOKAHEAD) % RING last held frame k + LOOKAHEAD - RING <= k - 5: its steps are behind the fence
             eng.fence()
             upload_next()
@@ -124,6 +130,8 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
         if not synchronous:
             for s in range(max(0, n_frames - 1 - LAG), n_frames - 1):
                 collect(s)
+        if before_close is not None:
+            before_close(eng)
     finally:
         ctx.host_free(pinned)
         eng.close()

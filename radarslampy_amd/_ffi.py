@@ -104,6 +104,7 @@ _SIGS = {
     "roam_comm_allreduce_f64": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),
     "roam_comm_barrier": (C.c_int32, [_vp]),
     "roam_bcast_keyframe": (C.c_int32, [_vp, C.c_int32, C.c_int32, _P(KeyframeHdr), _vp, C.c_int32, _vp, C.c_int64]),
+    "roam_keyframe_exchange": (C.c_int32, [_vp, C.c_int32]),
     "roam_remote_map_reserve": (C.c_int32, [_vp, C.c_int32]),
     "roam_remote_map_count": (C.c_int32, [_vp, _P(C.c_int64), _P(C.c_int32)]),
     "roam_remote_map_get": (C.c_int32, [_vp, C.c_int32, _P(KeyframeHdr), _P(C.c_int32), _vp, C.c_int32, _vp, C.c_int64]),

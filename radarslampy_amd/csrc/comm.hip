@@ -18,6 +18,7 @@ struct RcclApi {
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     char why[256] = {0};
 };
@@ -45,6 +46,7 @@ static RcclApi *rccl_api()
     BIND(CommUserRank, "ncclCommUserRank")
     BIND(Broadcast, "ncclBroadcast")
     BIND(AllReduce, "ncclAllReduce")
+    BIND(AllGather, "ncclAllGather")
     BIND(GetErrorString, "ncclGetErrorString")
 #undef BIND
     return &api;
@@ -164,3 +166,12 @@ int32_t roam_comm_bcast_bytes(roam_ctx *ctx, void *dev_buf, size_t bytes, int ro
 }
 
 int roam_comm_rank(const roam_ctx *ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+int roam_comm_world(const roam_ctx *ctx) { return ctx->comm ? ctx->comm->world : 1; }
+
+// every rank's `bytes` at send -> recv[rank * bytes ..] on every rank, enqueued on `st` (nothing waits on the host)
+int32_t roam_comm_allgather_bytes(roam_ctx *ctx, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+    if (!ctx->comm) { ROAM_SET_ERR(ctx, "communicator not initialised"); return ROAM_E_STATE; }
+    NCCL_TRY(ctx, rccl_api()->AllGather(send, recv, bytes, ncclChar, ctx->comm->comm, st));
+    return ROAM_OK;
+}

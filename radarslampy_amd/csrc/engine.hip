@@ -89,6 +89,16 @@ struct Engine {
     int rmap_cap = 0;
     int64_t rmap_n = 0;                             // keyframes received so far (slot = index % rmap_cap)
     std::vector<int32_t> rmap_root;                 // sending rank of each slot
+    // per-step keyframe exchange (roam_keyframe_exchange): fixed-size records, one all-gather per step on its own stream, the
+    // received keyframes appended on the device - the host never waits
+    uint8_t *kfx_send = nullptr, *kfx_recv = nullptr;
+    size_t kfx_rec = 0;                             // bytes of one record
+    int kfx_peaks = 0;                              // peaks carried per record
+    int64_t *rmap_n_dev = nullptr;                  // keyframes appended by the exchange (device-side count)
+    int32_t *rmap_root_dev = nullptr;               // their sending ranks, per slot
+    int64_t kfx_calls = 0;
+    hipStream_t st_comm = nullptr;
+    hipEvent_t ev_kfx = nullptr;
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t ev_join = nullptr, ev_pk0 = nullptr, ev_pk1 = nullptr;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[4] = {}, ev_g4[4] = {};                // back-end milestones stage A of step N+3 waits for
@@ -428,6 +438,61 @@ __global__ __launch_bounds__(256) void kf_pack_kernel(uint8_t *__restrict__ buf,
     for (int j = t; j < 2 * P; j += nt) pk[j] = ps[j];
 }
 
+// per-step exchange: this rank's record = the live keyframe of `lane` if the step just made it one (result flag bit 1), else an
+// empty record (n_features = -1); peaks are capped at `pk_cap` (n_peaks says how many travelled)
+__global__ __launch_bounds__(256) void kfx_pack_kernel(uint8_t *__restrict__ buf, int lane, const roam_lane_result *__restrict__ res,
+                                                       const double *__restrict__ kf_pose, const double *__restrict__ kf_vel,
+                                                       const int32_t *__restrict__ feat_n, const int32_t *__restrict__ kf_scan,
+                                                       const double *__restrict__ kf_und, const int32_t *__restrict__ peaks_n,
+                                                       const int32_t *__restrict__ peaks, int peaks_cap, int pk_cap)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const bool valid = (res[lane].flags & 2) != 0;
+    int n = feat_n[lane], P = peaks_n[lane];
+    if (n > KS) n = KS;
+    if (P > pk_cap) P = pk_cap;
+    if (t == 0) {
+        roam_keyframe_hdr *h = reinterpret_cast<roam_keyframe_hdr *>(buf);
+        for (int i = 0; i < 3; i++) { h->pose[i] = kf_pose[3 * lane + i]; h->velocity[i] = kf_vel[3 * lane + i]; }
+        h->n_features = valid ? n : -1; h->n_peaks = valid ? P : 0; h->scan = kf_scan[lane]; h->lane = lane;
+    }
+    if (!valid) return;
+    double *loc = reinterpret_cast<double *>(buf + KFB_LOCALS_OFF);
+    const double *src = kf_und + (size_t)lane * KS * 2;
+    for (int j = t; j < 2 * n; j += nt) loc[j] = src[j];
+    int32_t *pk = reinterpret_cast<int32_t *>(buf + KFB_PEAKS_OFF);
+    const int32_t *ps = peaks + (size_t)lane * peaks_cap * 2;
+    for (int j = t; j < 2 * P; j += nt) pk[j] = ps[j];
+}
+
+// Map.addKeyframe on this rank for every non-empty record of the gathered buffer, in rank order (one workgroup: the slot of
+// record r depends on the valid records before it)
+__global__ __launch_bounds__(256) void kfx_append_kernel(const uint8_t *__restrict__ recv, int world, size_t rec_bytes,
+                                                         uint8_t *__restrict__ rmap, size_t slot_bytes, int cap,
+                                                         int64_t *__restrict__ n_dev, int32_t *__restrict__ root_dev)
+{
+    __shared__ int64_t base;
+    if (threadIdx.x == 0) base = *n_dev;
+    __syncthreads();
+    int64_t cnt = base;
+    for (int r = 0; r < world; r++) {
+        const uint8_t *src = recv + (size_t)r * rec_bytes;
+        const roam_keyframe_hdr *h = reinterpret_cast<const roam_keyframe_hdr *>(src);
+        const int n = h->n_features, P = h->n_peaks;
+        if (n < 0) continue;
+        uint8_t *dst = rmap + (size_t)(cnt % cap) * slot_bytes;
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+        uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+        const size_t w_hdr = (KFB_HDR + (size_t)n * 16) / 4, w_pk0 = KFB_PEAKS_OFF / 4, w_pk = (size_t)P * 2;
+        for (size_t j = threadIdx.x; j < w_hdr; j += blockDim.x) d4[j] = s4[j];
+        for (size_t j = threadIdx.x; j < w_pk; j += blockDim.x) d4[w_pk0 + j] = s4[w_pk0 + j];
+        if (threadIdx.x == 0) root_dev[cnt % cap] = r;
+        cnt++;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *n_dev = cnt;
+}
+
 // f2 ingest: record i, rows 4 per workgroup (one wavefront per row): bytes [0, width) of every row from pinned host memory
 // into the pool.  Source rows start at arbitrary alignment (stride 3779), so a lane loads 16 bytes at byte granularity
 // through a packed unaligned vector type and stores them unaligned as well; the tail is copied byte-wise.
@@ -465,6 +530,8 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     if (e->scan_host) hipHostFree(e->scan_host);
     if (e->results_host) hipHostFree(e->results_host);
     for (auto &ev : e->ev_res) if (ev) hipEventDestroy(ev);
+    if (e->st_comm) { hipStreamSynchronize(e->st_comm); hipStreamDestroy(e->st_comm); }
+    if (e->ev_kfx) hipEventDestroy(e->ev_kfx);
     if (e->ev_pool) hipEventDestroy(e->ev_pool);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
@@ -881,6 +948,62 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
     return ROAM_OK;
 }
 
+// collective, NON-BLOCKING: every rank calls it once after each roam_engine_step with its own lane.  The rank's record (the lane's
+// new keyframe if the step made one, else empty) is packed on the device, one ncclAllGather of the fixed-size records runs on the
+// exchange stream behind the step's last kernel, and every non-empty record is appended to this rank's remote map on the device.
+// No host synchronisation: the step pipeline keeps running; roam_remote_map_count / _get wait for the exchange stream.
+int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane)
+{
+    ENGINE();
+    ARG_CHECK(ctx, lane >= 0 && lane < e->B);
+    if (!ctx->comm) { ROAM_SET_ERR(ctx, "keyframe_exchange: communicator not initialised"); return ROAM_E_STATE; }
+    if (e->rmap_cap <= 0) { ROAM_SET_ERR(ctx, "keyframe_exchange: reserve the remote map first"); return ROAM_E_STATE; }
+    if (e->nstep == 0) { ROAM_SET_ERR(ctx, "keyframe_exchange: no step enqueued"); return ROAM_E_STATE; }
+    const int world = roam_comm_world(ctx);
+    if (!e->kfx_send) {
+        e->kfx_peaks = std::min(e->cfg.peaks_cap, 32768);
+        e->kfx_rec = KFB_PEAKS_OFF + (size_t)e->kfx_peaks * 8;
+        if (!dalloc(ctx, e, &e->kfx_send, e->kfx_rec) || !dalloc(ctx, e, &e->kfx_recv, e->kfx_rec * (size_t)world) ||
+            !dalloc(ctx, e, &e->rmap_n_dev, 1) || !dalloc(ctx, e, &e->rmap_root_dev, (size_t)e->rmap_cap)) return ROAM_E_HIP;
+        HIP_TRY(ctx, hipMemsetAsync(e->rmap_n_dev, 0, sizeof(int64_t), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&e->st_comm, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_kfx, hipEventDisableTiming));
+    }
+    hipStream_t st = e->st_comm;
+    const int rs = (int)((e->nstep - 1) % RES_RING);
+    HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_res[rs], 0));            // the step's records (and with them its keyframe state) are final
+    hipLaunchKernelGGL(kfx_pack_kernel, dim3(16), dim3(256), 0, st, e->kfx_send, lane, e->results + (size_t)rs * e->B, e->kf_pose, e->kf_vel,
+                       e->feat_n, e->kf_scan, e->kf_und, e->peaks_n[e->pk], e->peaks_out[e->pk], e->cfg.peaks_cap, e->kfx_peaks);
+    HIP_TRY(ctx, hipGetLastError());
+    // the following steps overwrite what the pack kernel reads (keyframe state: the compute stream; the peak list of this ring slot:
+    // the peak stream, three steps on): their streams wait for the PACK, not for the collective
+    HIP_TRY(ctx, hipEventRecord(e->ev_kfx, st));
+    int32_t rc = roam_comm_allgather_bytes(ctx, e->kfx_send, e->kfx_recv, e->kfx_rec, st);
+    if (rc != ROAM_OK) return rc;
+    const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
+    hipLaunchKernelGGL(kfx_append_kernel, dim3(1), dim3(256), 0, st, e->kfx_recv, world, e->kfx_rec, e->rmap, slot_bytes, e->rmap_cap,
+                       e->rmap_n_dev, e->rmap_root_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    e->kfx_calls++;
+    return ROAM_OK;
+}
+
+// the exchange stream has drained: pull the device-side count and senders over to the host's bookkeeping
+static int32_t kfx_settle(roam_ctx *ctx, Engine *e)
+{
+    if (!e->kfx_send) return ROAM_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(e->st_comm));
+    int64_t n = 0;
+    HIP_TRY(ctx, hipMemcpy(&n, e->rmap_n_dev, sizeof(n), hipMemcpyDeviceToHost));
+    if (n > 0 && e->rmap_n > 0 && e->rmap_n != n) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
+    if (n > 0) {
+        e->rmap_n = n;
+        HIP_TRY(ctx, hipMemcpy(e->rmap_root.data(), e->rmap_root_dev, sizeof(int32_t) * (size_t)e->rmap_cap, hipMemcpyDeviceToHost));
+    }
+    return ROAM_OK;
+}
+
 int32_t roam_remote_map_reserve(roam_ctx *ctx, int32_t keyframes)
 {
     ENGINE();
@@ -898,6 +1021,7 @@ int32_t roam_remote_map_count(roam_ctx *ctx, int64_t *received, int32_t *residen
 {
     ENGINE();
     ARG_CHECK(ctx, received && resident);
+    { const int32_t rc_ = kfx_settle(ctx, e); if (rc_ != ROAM_OK) return rc_; }
     *received = e->rmap_n;
     *resident = (int32_t)std::min<int64_t>(e->rmap_n, e->rmap_cap);
     return ROAM_OK;
@@ -907,6 +1031,7 @@ int32_t roam_remote_map_get(roam_ctx *ctx, int32_t index, roam_keyframe_hdr *hdr
                             int32_t cap_pts, int32_t *peaks, int64_t peaks_cap)
 {
     ENGINE();
+    { const int32_t rc_ = kfx_settle(ctx, e); if (rc_ != ROAM_OK) return rc_; }
     const int resident = (int)std::min<int64_t>(e->rmap_n, e->rmap_cap);
     ARG_CHECK(ctx, hdr_out && index >= 0 && index < resident && cap_pts >= 0 && peaks_cap >= 0);
     // index 0 = the oldest keyframe still resident
@@ -997,6 +1122,10 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     //   A(N) waits for g4(N-3)   - that kernel reads the peak counts / scan indices of the same ring slot
     //   B(N) waits for A(N), KLT(N) waits for B(N)
     hipStream_t sA = ctx->stream2, sB = ctx->stream4;
+    if (e->kfx_calls) {                                     // a keyframe exchange is reading the previous step's keyframe / peak buffers
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e->ev_kfx, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream5, e->ev_kfx, 0));
+    }
     const int rs = (int)(e->nstep % RES_RING);            // ring slot of this step's result records
     if (e->nstep >= RES_RING) HIP_TRY(ctx, hipEventSynchronize(e->ev_res[rs]));   // its previous copy (8 steps ago) has long landed
     roam_lane_result *res_slot = e->results + (size_t)rs * B;

@@ -159,3 +159,5 @@ int32_t roam_doh_maxima_record_device(roam_ctx *ctx, const uint8_t *rec, int row
 // comm.hip: in-place byte broadcast of a device buffer on ctx->stream (asynchronous), this rank's index
 int32_t roam_comm_bcast_bytes(roam_ctx *ctx, void *dev_buf, size_t bytes, int root);
 int roam_comm_rank(const roam_ctx *ctx);
+int roam_comm_world(const roam_ctx *ctx);
+int32_t roam_comm_allgather_bytes(roam_ctx *ctx, const void *send, void *recv, size_t bytes, hipStream_t st);

@@ -71,6 +71,10 @@ class Engine:
     def remote_map_reserve(self, keyframes: int = 64):
         self.ctx.check(self.lib.roam_remote_map_reserve(self.ctx.h, int(keyframes)))
 
+    def keyframe_exchange(self, lane: int = 0):
+        """collective, non-blocking (roam_keyframe_exchange): call on every rank after each step"""
+        self.ctx.check(self.lib.roam_keyframe_exchange(self.ctx.h, int(lane)))
+
     def remote_map_count(self):
         """(keyframes received so far, keyframes resident in the ring)"""
         rec, res = C.c_int64(0), C.c_int32(0)

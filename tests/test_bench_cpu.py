@@ -75,3 +75,32 @@ def test_launcher_refuses_more_ranks_than_gpus(monkeypatch):
     src = open(BENCH).read()
     launcher = src[src.index("def visible_gpu_count"):src.index("# ------------------------------------------------------------------------------------------------ engines")]
     assert "_ffi" not in launcher and "Context(" not in launcher and "load_library" not in launcher
+
+
+def _check_config5(d, world, frames):
+    assert d["n_gpus"] == world and d["steps"] == frames - 1 and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["backend"] == "file" and c["frames"] == frames
+    # every keyframe of every rank arrived on rank 0 exactly once: the map holds the sum of what the ranks sent
+    assert len(c["keyframes_sent_per_rank"]) == world and c["map_received"] == sum(c["keyframes_sent_per_rank"]) > 0
+    assert c["senders"] == [r for r in range(world) if c["keyframes_sent_per_rank"][r]]
+
+
+def test_config5_exchange_schedule_world2_own_launcher():
+    """BASELINE config 5's loop shape - one sequence per rank, the keyframe exchange after EVERY step, keyframes falling on
+    different steps on different ranks - on the stub engine: the fixed schedule (one collective per step, empty records
+    when a rank has no new keyframe) delivers every keyframe to every rank"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--config5", "--dry-engine", "--c5-frames", "41"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_config5(_line(r.stdout), 2, 41)
+
+
+def test_config5_exchange_schedule_world8_torch_distributed_run():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", BENCH, "--gpus", "8", "--config5", "--dry-engine", "--c5-frames", "21"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_config5(_line(r.stdout), 8, 21)

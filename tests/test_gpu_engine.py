@@ -364,3 +364,58 @@ def test_pageable_host_memory_is_refused_by_the_async_upload(sequences):
     eng.synchronize()
     eng.close()
     ctx.close()
+
+
+def test_rccl_keyframe_exchange_in_the_loop_world1(sequences):
+    """BASELINE config 5's loop on one GPU (communicator of size 1): roam_keyframe_exchange after EVERY step, never a host
+    synchronisation in between.  The remote map then holds exactly the keyframes the steps made (result flag bit 1), in step
+    order, each equal to the lane's live keyframe right after its step; the odometry is untouched by the exchange."""
+    import tempfile
+    from radarslampy_amd import _ffi
+    from radarslampy_amd import distributed as D
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = sequences[0]
+    T = len(recs)
+
+    def run(exchange):
+        ctx = _ffi.Context(0)
+        eng = Engine(1, T, ctx=ctx, retrack_on_device=True)
+        for t in range(T):
+            eng.upload_scan(t, recs[t])
+        eng.init_lane(0, 0, feat[:90], poses[0])
+        comm = D.RcclComm(ctx, D.FileRendezvous(tempfile.mkdtemp(prefix="roam_rdv_"), 0, 1)) if exchange else None
+        out, live = [], []
+        try:
+            if exchange:
+                eng.remote_map_reserve(16)
+            order = list(range(1, T)) + list(range(T - 2, -1, -1))
+            for k, t in enumerate(order):
+                eng.step([t])
+                if exchange:
+                    eng.keyframe_exchange(0)
+                if exchange is False:                     # the reference run: read the keyframe a step leaves behind (blocking)
+                    r = eng.results()[0]
+                    live.append(eng.live_keyframe(0) if r["new_keyframe"] else None)
+            for k in range(len(order) - min(8, len(order)), len(order)):
+                out.append(eng.results(k)[0])
+            got = None
+            if exchange:
+                n_rec, n_res = eng.remote_map_count()
+                got = [eng.remote_map_get(i) for i in range(n_res)]
+                assert n_rec == n_res
+        finally:
+            if comm is not None:
+                comm.close()
+            eng.close()
+            ctx.close()
+        return out, live, got
+
+    ref, live, _ = run(False)
+    out, _, got = run(True)
+    assert [r["pose"].tobytes() for r in out] == [r["pose"].tobytes() for r in ref]
+    want = [kf for kf in live if kf is not None]
+    assert len(want) >= 1 and len(got) == len(want), (len(want), len(got))
+    for g, w in zip(got, want):
+        assert g["root"] == 0 and g["lane"] == 0 and g["scan"] == w["scan"]
+        for key in ("pose", "velocity", "prunedUndistortedLocals", "peaks"):
+            assert np.array_equal(g[key], w[key][:32768] if key == "peaks" else w[key]), key
