@@ -650,6 +650,55 @@ __device__ __forceinline__ bool nx_sub_adj_tiny(const CqCtx &c, const NxSet &CD,
     return true;
 }
 
+// The long forced prefix of the walk, taken in one go.  In a scan pair's graph most of the clique is UNIVERSAL inside cand (adjacent to
+// every other candidate): such a vertex has the maximum pivot key |cand| - 1, so networkx picks the first of them (in subg's
+// iteration order) as pivot, ext_u = {pivot}, and descends - one level per universal vertex, omega minus a handful of levels in
+// which nothing is decided.  While subg and cand keep every key in its own slot (ascending iteration) those levels are known
+// in advance: T = the vertices of subg with key |cand| - 1 only ever shrinks (T' = T & adj[v] when v is taken; nobody joins), the
+// pivots are its members in ascending order, and a level is nothing but "Q += v, cand -= v, subg &= adj[v]".  The bulk stops
+// where the real walk has something to do: the first tied vertex lies outside cand (an excluded vertex is the pivot), a child set
+// would need an explicit table, or one candidate is left.
+__device__ void nx_bulk(const CqCtx &c, NxSet &subg, NxSet &cand, uint64_t &RF, int &size)
+{
+    if (!subg.ident || !cand.ident || cand.used < 2) return;
+    const int lane = c.lane, nw = c.nw;
+    __syncthreads();
+    if (lane < 16) c.sw[lane] = cand.live;
+    __syncthreads();
+    uint64_t T = 0;
+    const int full = cand.used - 1;
+    for (int ch = 0; ch < nw; ch++) {
+        const uint64_t bits = bs_word(subg.live, ch);
+        if (!bits) continue;
+        const bool in = (bits >> lane) & 1ull;
+        int d = -1;
+        if (in) {
+            const int u = ch * 64 + lane;
+            d = 0;
+            for (int w = 0; w < nw; w++) d += __popcll(c.A[(int64_t)u * c.as + w] & c.sw[w]);
+        }
+        const uint64_t b = __ballot(in && d == full);
+        if (lane == ch) T = b;
+        if (__ballot(in && d > full)) { T = 0; break; }                 // an excluded vertex adjacent to ALL of cand is the pivot: nothing to skip
+    }
+    __syncthreads();
+    for (;;) {
+        if (cand.used < 2) return;
+        const int v = bs_first(T);
+        if (v < 0) return;
+        const uint64_t bv = bit_if(lane, v);
+        if (!__ballot((cand.live & bv) != 0)) return;                   // an excluded vertex ties with the universal ones: it is the pivot
+        const uint64_t row = (lane < nw) ? c.A[(int64_t)v * c.as + lane] : 0ull;
+        const uint64_t nc = cand.live & ~bv, ns = subg.live & row;
+        const int ncn = cand.used - 1, nsn = bs_count(ns);
+        if (bs_last(nc) >= nx_incr_size(ncn) || bs_last(ns) >= nx_incr_size(nsn)) return;    // a child needs an explicit table
+        RF |= bv; size++;
+        cand.live = nc; cand.used = ncn; cand.mask = nx_incr_size(ncn) - 1;
+        subg.live = ns; subg.used = nsn; subg.mask = nx_incr_size(nsn) - 1;
+        T &= row;
+    }
+}
+
 // RF = the first clique of size omega in networkx.find_cliques order.  false: the bounded searches ran out of nodes.
 __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uint64_t WIT, uint64_t &RF)
 {
@@ -670,6 +719,9 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
     for (;;) {
         if (entered) {
             entered = false;
+#ifndef NX_EXP_NOBULK
+            nx_bulk(c, subg, cand, RF, size);
+#endif
             const int pu = nx_pivot(c, subg, cand.live);
             const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
             const int pdeg = bs_count(prow);
