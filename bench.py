@@ -590,7 +590,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
                 W_ = 2 * (eng.cfg.clip // 2)
                 det_bytes = eng.cfg.rows * eng.cfg.clip + 2 * 8.0 * W_ * W_
                 out["config"]["whole_step_algorithmic_GBs"] = round((13.07e6 * B + det_bytes * float(np.mean(rps))) / (dt / args.steps) / 1e9, 1)
-            out["roofline"] = roofline(eng, args, B, out["config"].get("retrack_fraction") or 0.0, live)
+            out["roofline"] = roofline(eng, args, B // max(1, len(engs)), out["config"].get("retrack_fraction") or 0.0, live)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, seqs, cyc)
     for en in engs:
@@ -634,8 +634,13 @@ def pmc_record(kname):
             if not k:
                 continue
             src = os.path.join(ROOT, "radarslampy_amd", "csrc", k.get("source_file", ""))
-            if not k.get("source_sha16") or not os.path.isfile(src) or _sha16(src) != k["source_sha16"]:
-                return None, cand + " (stale: the kernel's source changed since the PMC passes)"
+            if k.get("source_fingerprint"):                      # round 4: translation unit + headers + build flags, hashed when MEASURED
+                from radarslampy_amd import build as _build
+                fresh = os.path.isfile(src) and _build.fingerprint([k["source_file"]]) == k["source_fingerprint"]
+            else:
+                fresh = bool(k.get("source_sha16")) and os.path.isfile(src) and _sha16(src) == k["source_sha16"]
+            if not fresh:
+                return None, cand + " (stale: the kernel's source, a header or the build flags changed since the PMC passes)"
             return dict(k, units_per_launch=tj.get("units_per_launch", tj.get("lanes"))), cand
         except Exception:                                              # noqa: BLE001
             continue
@@ -643,7 +648,9 @@ def pmc_record(kname):
 
 
 def roofline(eng, args, B, retrack_fraction, live_all):
-    """roofline of the dominant HBM-streaming kernel of a step.  Candidates: the three front-end kernels (once per lane and
+    """(B = the lanes of ONE engine - `eng`, engine 0: its isolated re-launches, its live event timings and its per-step detection
+    counts all refer to that engine, also with --engines > 1)
+    roofline of the dominant HBM-streaming kernel of a step.  Candidates: the three front-end kernels (once per lane and
     step) and the two image-scale kernels of the feature re-detection (once per RETRACKING lane: weighted by the observed
     retrack fraction).  `avg_launch_ms` is the kernel's average launch duration over the K timed steps from HIP event pairs the
     engine records on the stream the kernel runs on (roam_engine_kernel_avg / roam_engine_kernel_chunk_ms, read right after the timed

@@ -5,6 +5,8 @@ set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_det
 rm -rf $OUT; mkdir -p $OUT
+# what is being measured: the hash of retrack.hip + every header + the build flags, taken NOW (bench.py compares it with the tree it runs)
+python3 radarslampy_amd/build.py --fingerprint retrack.hip > $OUT/source_fingerprint.txt
 ARGS="profiles/time_doh.py ${LANES:-512}"
 run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ARGS > $OUT/$name.log 2>&1; }
 run A SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD

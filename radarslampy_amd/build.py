@@ -19,6 +19,19 @@ NO_PAIRING = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllv
 EXTRA = {"retrack.hip": NO_PAIRING}
 
 
+def fingerprint(sources):
+    """hash of what decides a kernel's machine code: the named translation units, every header of csrc/, and this file's flags.
+    The PMC records under profiles/ carry it (taken when the counters are MEASURED) and bench.py reports their traffic figures only
+    while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(sources)] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    h.update(repr((FLAGS, sorted((k, v) for k, v in EXTRA.items() if k in sources))).encode())
+    return h.hexdigest()[:16]
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -58,4 +71,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--fingerprint":
+        print(fingerprint(sys.argv[2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))
