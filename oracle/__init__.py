@@ -11,8 +11,9 @@ Layout
 
 Parity status (details in DESIGN.md §4):
   PINNED by goldens produced by the reference itself (tests/golden/*.npz, make_goldens.py):
-      getPointCloudPolarInd, ssc, calculateTransformSVD, rejectOutliers (size always, set when
-      the maximum clique is unique), MotionDistortionSolver (error_vector, undistort,
+      getPointCloudPolarInd, ssc, calculateTransformSVD, rejectOutliers (the reference's MASK, ties between maximum
+      cliques included: networkx.find_cliques order restated in oracle/c/clique.c and checked against the live
+      networkx / CPython of this image), MotionDistortionSolver (error_vector, undistort,
       compute_time_deltas, optimize_library), utils SE(2) helpers, record decode,
       Tracker.track glue, Keyframe glue.
   PINNED by outputs of the reference's own cv2 / scikit-image / SciPy / NumPy stack that the reference
@@ -26,6 +27,9 @@ Parity status (details in DESIGN.md §4):
       +-1 grey-level pixels of the reference's warp: its OpenCV build takes the map radius from IPP's
       ippsMagnitude_32f rather than a correctly rounded sqrt; every identified pixel sits on a rounding tie of
       rho*32.  Not reproducible without that binary, and not a property of the algorithm.
+  PINNED end to end by the poses the reference printed into img/roam_mapping/tiny_traj/*.jpg (tests/golden/tiny_traj.npz,
+  make_tiny_traj.py; tests/test_oracle_tiny_traj.py): OdometryPipeline reproduces frames 1-3 (and 5, given the reference's
+  frame-4 clique) to print precision; DESIGN.md §4 has the per-frame table of what accounts for the rest.
 """
 import ctypes as C
 import os
