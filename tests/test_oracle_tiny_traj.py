@@ -7,7 +7,12 @@ What is reproduced, and what is not (DESIGN.md section 4 has the table):
   frames 1-3   EST Pose, EST Deltas and RMSE to print precision - with the reference's clique tie-break (4-, 14- and 2-way ties
                between maximum cliques on these pairs; the lexicographic rule of rounds 1-3 was 2-10 mm off on frame 1);
   frame 4      the reference's numbers are those of the SECOND of the nine tied maximum cliques in networkx order on our
-               graph (shown below by enumerating the nine); with it frame 5 follows to print precision;
+               graph (shown below by enumerating the nine); with it frame 5 follows to print precision.  WHY the reference
+               meets that clique first: ONE adjacent swap in the response order of two near-equal DoH maxima of frame 2 (relative
+               difference 2.8e-4; the reference's IPP-built warp differs from ours at a few dozen grey levels per image and swaps
+               such a pair on frame 9 too) permutes the ties of adaptiveNMS's unstable sort, the same
+               features come out in another order, the graph's nodes are numbered differently - and then frames 1-5 ALL
+               reproduce the reference's prints with the first clique, nothing chosen by hand;
   frames 6-10  the reference's run holds a feature set ours does not (no clique of our frame-6 graph gives its pose); the
                poses stay within 0.15 m / 0.3 deg and the RMSE within 0.02 of the reference's.
 """
@@ -102,6 +107,49 @@ def test_frame_4_is_the_second_tied_clique_and_frame_5_follows(data, monkeypatch
             assert np.abs(_printed(nxt["pose"]) - traj["roam_mapping_est_pose"][4]).max() <= PRINT
     monkeypatch.setattr(oracle, "rejectOutliers", real)
     assert found["n"] == 9 and hits == [1], (found, hits)
+
+
+def _detect_with_swap(swaps, frame_of):
+    """getFeatures with the response-ordered candidate list of the named frames perturbed: rows i and i + 1 exchanged before
+    _prune_blobs (two maxima whose responses are nearly equal come out of peak_local_max in the other order)"""
+    W = 2024
+
+    def detect(cart):
+        f = frame_of[0]
+        sig = np.linspace(0.01, 10, 3)
+        rcs, val, _ = oracle.doh_maxima(np.asarray(cart, np.float64), sig, .0005)
+        idx = np.argsort(-val, kind="stable")
+        if f in swaps:
+            i = swaps[f]
+            assert abs(val[idx[i]] - val[idx[i + 1]]) / val[idx[i]] < 1e-3            # a near-tie, nothing else
+            idx[[i, i + 1]] = idx[[i + 1, i]]
+        bl = rcs[idx].astype(np.float64)
+        bl[:, 2] = sig[rcs[idx][:, 2]]
+        sel = oracle.adaptiveNMS((W, W), oracle.prune_blobs(bl, 0.5))
+        return np.fliplr(sel[:, :2])
+    return detect
+
+
+def test_one_swapped_near_tie_of_frame_2_explains_frames_4_and_5(data):
+    """frames 1-5 against the reference's prints with the FIRST clique networkx meets, after exchanging the 522nd and 523rd of the
+    ~600 response-ordered DoH maxima of frame 2 (responses 2.8e-4 apart): every frame within print precision.  (Three other
+    near-ties of that frame - 264, 338, 485 - do the same; without the swap frame 4 is 16 / 27 mm off.)"""
+    traj, pay = data
+    frame = [0]
+    detect = _detect_with_swap({2: 521}, frame)
+    cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), detect(cart0))
+    plain = oracle.append_dedupe(np.empty((0, 2)), _detect(cart0))
+    assert np.array_equal(feat0, plain)                                         # (frame 0 is untouched)
+    pipe = oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), feat0, traj["gt_pose"][0], detect=detect, payload_off=0, clip=pay.shape[2])
+    est = [traj["gt_pose"][0]]
+    for t in range(1, 6):
+        frame[0] = t
+        out = pipe.step(np.ascontiguousarray(pay[t]))
+        est.append(out["pose"].copy())
+        assert np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1]).max() <= PRINT, t
+        assert np.abs(_deltas(est[-2], est[-1]) - traj["roam_mapping_est_deltas"][t - 1]).max() <= PRINT, t
+        assert abs(_rmse(traj["gt_pose"][:t + 1], est) - traj["roam_mapping_rmse"][t - 1]) <= 5.1e-3, t
 
 
 def test_frames_6_to_10_stay_in_the_neighbourhood(data):
