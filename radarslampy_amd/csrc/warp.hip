@@ -399,12 +399,9 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             }
             // (scalar multiplies here: a packed one makes the compiler pack the three adds above as well, at the
             // price of a dozen register moves)
-            // (img * 255).astype(uint8): v_cvt_pk_u8_f32 truncates like the reference's cast AND places the byte - 2 instructions per
-            // pixel instead of 4 (multiply, convert, mask, shift-or); round 4: 11.0 -> 10.6 ms per 4096 scans, bit-identical
-            uint32_t pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(vq[0], 255.f), 0, 0u);
-            pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(vq[1], 255.f), 1, pk);
-            pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(vq[2], 255.f), 2, pk);
-            pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(vq[3], 255.f), 3, pk);
+            // (v_cvt_pk_u8_f32 would convert AND place the byte, but it ROUNDS to nearest where the reference's cast truncates - 11.0 ->
+            // 10.6 ms with wrong bytes; fed the floor it is exact and SLOWER, 11.5 ms: round 4, measured and dropped)
+            const uint32_t pk = quant_u8(vq[0]) | (quant_u8(vq[1]) << 8) | (quant_u8(vq[2]) << 16) | (quant_u8(vq[3]) << 24);
             const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
             const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
             const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));

@@ -155,3 +155,35 @@ def test_peaks_u8_long_plateaus(ctx):
     want = oracle.peaks_from_record_u8(rec, off, clip)
     assert want.shape[0] > 300
     assert np.array_equal(got, want)
+
+
+def test_clique_tie_break_in_every_table_regime(ctx):
+    """the networkx-order walk where its set tables take every form: K up to 520 (tables of 512 slots with keys beyond them: the
+    fixed-point replay in LDS), sparse graphs (small neighbour sets iterate in hashed, not ascending, order; `cand - adj[u]` takes
+    CPython's copy-and-discard branch), dense tie-heavy graphs (the register replay, the bulk prefix) - the mask equals the
+    oracle's networkx-order clique on every one (the oracle itself is pinned against the live networkx on CPU)"""
+    rng = np.random.default_rng(2024)
+    cases = []
+    for K in (9, 33, 70, 129, 200, 300, 520):
+        # scan-pair-like: a rigid set + movers + jitter straddling the threshold
+        p = rng.uniform(60, 1960, size=(K, 2)).astype(np.float32)
+        n = (p + rng.normal(0, 1.9, size=(K, 2))).astype(np.float32)
+        mv = rng.permutation(K)[:max(1, K // 4)]
+        n[mv] += rng.normal(0, 15, size=(len(mv), 2)).astype(np.float32)
+        cases.append((p, n))
+    for K in (40, 150, 400):
+        # sparse: almost everything moves on its own, a few small rigid groups
+        p = rng.uniform(60, 1960, size=(K, 2)).astype(np.float32)
+        n = (p + rng.normal(0, 40, size=(K, 2))).astype(np.float32)
+        for g in range(K // 12):
+            idx = rng.permutation(K)[:6]
+            n[idx] = p[idx] + rng.normal(0, 25, size=2).astype(np.float32) + rng.normal(0, 0.8, size=(6, 2)).astype(np.float32)
+        cases.append((p, n))
+    differ = 0
+    for p, n in cases:
+        mask, n_in, flags, adj = ctx.reject_outliers(p, n, oracle.DIST_THRESHOLD_PX, want_adj=True)
+        size, omask, _ = oracle.max_clique_nx(adj)
+        assert flags & 1
+        assert n_in == size and np.array_equal(mask, omask), len(p)
+        differ += not np.array_equal(omask, oracle.max_clique_lex(adj)[1])
+    assert differ >= 4, differ
