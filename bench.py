@@ -452,15 +452,20 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             slots_ = min(B // len(engs), args.retrack_slots or 512)
             nst = min(args.steps, 64)
             n_step = [stat.get("per_step", {}).get(pre + args.warmup + k, 0) for k in range(args.steps - nst, args.steps)]
+            # (chunks of fewer than 200 detections take the two-pass integral kernels - three times the traffic of the one-sweep kernel
+            # whose algorithmic bytes the roofline uses - so they are left out of the live average of BOTH kernels)
+            units_tot = 0
             for k in knames[3:]:
                 m = eng.kernel_chunk_ms(k, nst)
-                tot, nb = 0.0, 0
+                tot, nb, units_tot = 0.0, 0, 0
                 for srow, n_ in zip(m[-len(n_step):], n_step[-len(m):]):
-                    busy = min(len(srow), -(-n_ // slots_))
-                    tot += float(srow[:busy].sum()); nb += busy
+                    for c_ in range(min(len(srow), -(-n_ // slots_))):
+                        held = min(slots_, n_ - c_ * slots_)
+                        if held >= 200:
+                            tot += float(srow[c_]); nb += 1; units_tot += held
                 live[k] = tot / nb if nb else 0.0
                 live["doh_busy_launches"] = nb
-            live["doh_units_per_launch"] = float(sum(n_step)) / live["doh_busy_launches"] if live.get("doh_busy_launches") else 0.0
+            live["doh_units_per_launch"] = float(units_tot) / live["doh_busy_launches"] if live.get("doh_busy_launches") else 0.0
     if comm is not None:
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
 

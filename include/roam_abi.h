@@ -285,7 +285,9 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
  * *steps_out (<= last_steps, <= 64) steps, oldest first; -1 for a step without device-side detection.  A step launches
  * ceil(lanes / retrack_slots) chunks (the first 16 are traced) whatever the number n of lanes that re-detect - only the device
  * knows it; chunk c holds clamp(n - c * retrack_slots, 0, retrack_slots) detections, n is in the step's result records.
- * cap (floats) >= last_steps * 16 always suffices */
+ * cap (floats) >= last_steps * 16 always suffices.  "doh_integral": a chunk of fewer than 200 detections ran the two-pass kernels
+ * (three times the one-sweep kernel's traffic; both forms are launched, the one whose regime it is not returns at once) - leave such
+ * chunks out of a roofline average, as bench.py does */
 int32_t roam_engine_kernel_chunk_ms(roam_ctx *ctx, const char *name, int32_t last_steps, float *ms_out, int32_t cap, int32_t *chunks,
                                     int32_t *steps_out);
 /* time `reps` launches of the dominant streaming kernel (warp+quantise of all lanes) with
