@@ -448,6 +448,24 @@ __device__ __attribute__((noinline)) void nx_build_small(int lane, uint64_t *occ
     const bool copy = __builtin_amdgcn_readfirstlane((int)copy_) != 0;
     int kv = lane < n ? (int)seq[lane] : 0, sv = 0;
     uint64_t o0 = 0, o1 = 0;
+    // No two keys with the same home slot in the FINAL table => every key finds its home free whenever it is inserted: the layout is
+    // "key at key & mask" whatever the order, and the earlier tables (which only decide that order) need no replay either.  The rule
+    // for most sets of 19..76 members here (128 slots, ids below ~170: only k and k + 128 can meet).
+    {
+        __shared__ uint32_t hb[4];
+        if (lane < 4) hb[lane] = 0u;
+        __syncthreads();
+        const int h = kv & (size - 1);
+        if (lane < n) atomicOr(&hb[h >> 5], 1u << (h & 31));
+        __syncthreads();
+        const uint64_t b0 = (uint64_t)hb[0] | ((uint64_t)hb[1] << 32), b1 = (uint64_t)hb[2] | ((uint64_t)hb[3] << 32);
+        __syncthreads();
+        if (__popcll(b0) + __popcll(b1) == n) {
+            if (lane < n) tab[h] = (uint16_t)kv;
+            *occ_out = lane == 0 ? b0 : (lane == 1 ? b1 : 0ull);
+            return;
+        }
+    }
     // the tables the set goes through: 5 keys in 8 slots, 19 in 32, then all of them in the final one
     if (!copy && n >= 5 && size > 8) { nx_run_small(lane, kv, sv, o0, o1, 5, 7); kv = nx_reorder_small(lane, kv, sv, o0, 5); }
     if (!copy && n >= 19 && size > 32) { nx_run_small(lane, kv, sv, o0, o1, 19, 31); kv = nx_reorder_small(lane, kv, sv, o0, 19); }
