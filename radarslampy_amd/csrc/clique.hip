@@ -269,6 +269,7 @@ struct NxSet {
     uint16_t *tab;      // explicit layout: slot -> key
     int mask, used;
     bool ident;
+    bool perfect;       // explicit layout in which every key sits at its home slot key & mask (no key was ever displaced)
 };
 struct NxLds { uint16_t *tab[6], *seq, *seq2, *seq3, *slot; uint32_t *T; int ts; };
 
@@ -440,7 +441,7 @@ __device__ __forceinline__ int nx_reorder_small(int lane, int kv, int sv, uint64
     const int r = __popcll(o0 & ((1ull << (sv & 63)) - 1ull));       // (a table of <= 32 slots) rank of the lane's slot
     return __builtin_amdgcn_ds_permute((lane < m ? r : lane) << 2, kv);
 }
-__device__ __attribute__((noinline)) void nx_build_small(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab)
+__device__ __attribute__((noinline)) int nx_build_small(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab)
 {
     // (arguments of an out-of-line function arrive in vector registers: say that these are wave-uniform, or every loop below
     // becomes a divergent one and v_readlane a waterfall)
@@ -463,7 +464,7 @@ __device__ __attribute__((noinline)) void nx_build_small(int lane, uint64_t *occ
         if (__popcll(b0) + __popcll(b1) == n) {
             if (lane < n) tab[h] = (uint16_t)kv;
             *occ_out = lane == 0 ? b0 : (lane == 1 ? b1 : 0ull);
-            return;
+            return 1;
         }
     }
     // the tables the set goes through: 5 keys in 8 slots, 19 in 32, then all of them in the final one
@@ -472,6 +473,7 @@ __device__ __attribute__((noinline)) void nx_build_small(int lane, uint64_t *occ
     nx_run_small(lane, kv, sv, o0, o1, n, size - 1);
     if (lane < n) tab[sv] = (uint16_t)kv;
     *occ_out = lane == 0 ? o0 : (lane == 1 ? o1 : 0ull);
+    return 0;
 }
 
 // table of a set built by inserting seq[0..n) one by one (copy = false: growth 8 -> 32 -> 128 -> 512 -> 2048, set_add_entry
@@ -483,6 +485,7 @@ __device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq
     if (copy) { if (n >= 5) while (size <= 2 * n) size <<= 1; }
     else size = n < 5 ? 8 : n < 19 ? 32 : n < 77 ? 128 : n < 307 ? 512 : 2048;
     D.used = n; D.tab = tab; D.occ = 0; D.mask = size - 1;
+    D.perfect = false;
     D.ident = maxkey < size;
 #ifdef NX_EXP_NOBUILD
     D.ident = true;
@@ -490,9 +493,10 @@ __device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq
     if (D.ident) return;
     if (size <= 128 && n <= 64) {
         uint64_t o;
-        nx_build_small(c.lane, &o, seq, n, size, copy, tab);
+        const int pf = nx_build_small(c.lane, &o, seq, n, size, copy, tab);
         __syncthreads();
         D.occ = o;
+        D.perfect = __builtin_amdgcn_readfirstlane(pf) != 0;
         return;
     }
     const uint16_t *P = seq;
@@ -534,7 +538,7 @@ __device__ void nx_filter_build(const CqCtx &c, NxLds &L, NxSet &D, const NxSet 
     D.live = X;
     // the common case needs no replay at all: every key below the table size => each key in its own slot, whatever the order
     const int n0 = bs_count(X), mk0 = bs_last(X);
-    if (mk0 < nx_incr_size(n0)) { D.used = n0; D.tab = tab; D.occ = 0; D.mask = nx_incr_size(n0) - 1; D.ident = true; return; }
+    if (mk0 < nx_incr_size(n0)) { D.used = n0; D.tab = tab; D.occ = 0; D.mask = nx_incr_size(n0) - 1; D.ident = true; D.perfect = false; return; }
     int maxkey;
     const int n = nx_seq(c, ITER, F, L.seq, maxkey);
     nx_build(c, L, D, L.seq, n, maxkey, false, tab);
@@ -543,7 +547,7 @@ __device__ void nx_filter_build(const CqCtx &c, NxLds &L, NxSet &D, const NxSet 
 // adj[q] = {v for v in G[q] if v != q}: ascending insertion of the row
 __device__ void nx_adj_set(const CqCtx &c, NxLds &L, NxSet &D, uint64_t row, uint16_t *tab)
 {
-    NxSet asc; asc.live = row; asc.ident = true; asc.mask = 0; asc.used = 0; asc.occ = 0; asc.tab = nullptr;
+    NxSet asc; asc.live = row; asc.ident = true; asc.perfect = false; asc.mask = 0; asc.used = 0; asc.occ = 0; asc.tab = nullptr;
     nx_filter_build(c, L, D, asc, ~0ull, tab);
 }
 
@@ -555,7 +559,7 @@ __device__ void nx_and_adj(const CqCtx &c, NxLds &L, NxSet &D, const NxSet &S, i
     // in ascending order, and so does the result's insertion sequence - no table of adj[q] is needed (nearly always: 77+ neighbours
     // sit in 512 slots)
     if (bs_last(row) < nx_incr_size(deg)) {
-        NxSet asc; asc.live = row; asc.ident = true; asc.mask = 0; asc.used = deg; asc.occ = 0; asc.tab = nullptr;
+        NxSet asc; asc.live = row; asc.ident = true; asc.perfect = false; asc.mask = 0; asc.used = deg; asc.occ = 0; asc.tab = nullptr;
         nx_filter_build(c, L, D, asc, S.live, tab);
         return;
     }
@@ -676,9 +680,25 @@ __device__ __forceinline__ bool nx_sub_adj_tiny(const CqCtx &c, const NxSet &CD,
 // pivots are its members in ascending order, and a level is nothing but "Q += v, cand -= v, subg &= adj[v]".  The bulk stops
 // where the real walk has something to do: the first tied vertex lies outside cand (an excluded vertex is the pivot), a child set
 // would need an explicit table, or one candidate is left.
+// occupancy of a perfect table of mask + 1 >= 128 slots from its members: slot word h = OR of the key words w with w = h mod (words)
+__device__ __forceinline__ uint64_t nx_fold_occ(uint64_t live, int mask, int lane, int nw)
+{
+    const int hw = (mask + 1) >> 6;
+    uint64_t o = 0;
+    for (int w = 0; w < nw; w++) {
+        const uint64_t x = bs_word(live, w);
+        if (lane == (w & (hw - 1))) o |= x;
+    }
+    return o;
+}
+
 __device__ void nx_bulk(const CqCtx &c, NxSet &subg, NxSet &cand, uint64_t &RF, int &size)
 {
-    if (!subg.ident || !cand.ident || cand.used < 2) return;
+    // "every key in its own slot" comes in two forms: all keys below the table size (ident: ascending iteration) or an explicit table
+    // of 128+ slots without a displaced key (perfect: iteration by key & mask; a subset of a perfect table re-inserted into a table
+    // of the SAME size is perfect again, whatever the insertion order - so a forced level is still "clear the bit")
+    const bool sp = !subg.ident && subg.perfect && subg.mask >= 127, cp = !cand.ident && cand.perfect && cand.mask >= 127;
+    if (!(subg.ident || sp) || !(cand.ident || cp) || cand.used < 2) return;
     const int lane = c.lane, nw = c.nw;
     __syncthreads();
     if (lane < 16) c.sw[lane] = cand.live;
@@ -700,20 +720,34 @@ __device__ void nx_bulk(const CqCtx &c, NxSet &subg, NxSet &cand, uint64_t &RF, 
         if (__ballot(in && d > full)) { T = 0; break; }                 // an excluded vertex adjacent to ALL of cand is the pivot: nothing to skip
     }
     __syncthreads();
+    const int hws = sp ? ((subg.mask + 1) >> 6) - 1 : 0xffff;           // iteration order of subg: by (word & hws) * 64 + bit
+    bool folded = false;
     for (;;) {
-        if (cand.used < 2) return;
-        const int v = bs_first(T);
-        if (v < 0) return;
+        if (cand.used < 2) break;
+        // the first tied vertex in subg's iteration order
+        int key = 0x7fffffff;
+        if (T) { const int bpos = __ffsll((long long)T) - 1; key = ((((lane & hws) << 6) | bpos) << 11) | (lane * 64 + bpos); }
+        key = wave_min_i(key);
+        if (key == 0x7fffffff) break;
+        const int v = key & 2047;
         const uint64_t bv = bit_if(lane, v);
-        if (!__ballot((cand.live & bv) != 0)) return;                   // an excluded vertex ties with the universal ones: it is the pivot
+        if (!__ballot((cand.live & bv) != 0)) break;                    // an excluded vertex ties with the universal ones: it is the pivot
         const uint64_t row = (lane < nw) ? c.A[(int64_t)v * c.as + lane] : 0ull;
         const uint64_t nc = cand.live & ~bv, ns = subg.live & row;
         const int ncn = cand.used - 1, nsn = bs_count(ns);
-        if (bs_last(nc) >= nx_incr_size(ncn) || bs_last(ns) >= nx_incr_size(nsn)) return;    // a child needs an explicit table
+        // the children keep "every key in its own slot": ident sets while their keys stay below the (shrinking) table size, perfect
+        // sets while the table size does not change
+        if (cp ? (nx_incr_size(ncn) != cand.mask + 1) : (bs_last(nc) >= nx_incr_size(ncn))) break;
+        if (sp ? (nx_incr_size(nsn) != subg.mask + 1) : (bs_last(ns) >= nx_incr_size(nsn))) break;
         RF |= bv; size++;
-        cand.live = nc; cand.used = ncn; cand.mask = nx_incr_size(ncn) - 1;
-        subg.live = ns; subg.used = nsn; subg.mask = nx_incr_size(nsn) - 1;
+        cand.live = nc; cand.used = ncn; if (!cp) cand.mask = nx_incr_size(ncn) - 1;
+        subg.live = ns; subg.used = nsn; if (!sp) subg.mask = nx_incr_size(nsn) - 1;
         T &= row;
+        folded = true;
+    }
+    if (folded) {                                                       // the explicit tables lose the slots of what left
+        if (cp) cand.occ = nx_fold_occ(cand.live, cand.mask, lane, nw);
+        if (sp) subg.occ = nx_fold_occ(subg.live, subg.mask, lane, nw);
     }
 }
 
@@ -725,7 +759,7 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
     uint64_t elist = 0;                                                 // ext_u of <= 4 members: packed pop order (nx_sub_adj_tiny)
     int en = -1;                                                        // ... its remaining count, -1 = ext is the set `ext`
     int cur = 0;
-    cand.live = ALL; cand.ident = true; cand.used = Kb; cand.occ = 0; cand.tab = L.tab[2];                     // set(G): every key < table size
+    cand.live = ALL; cand.ident = true; cand.perfect = false; cand.used = Kb; cand.occ = 0; cand.tab = L.tab[2];                     // set(G): every key < table size
     cand.mask = (Kb < 5 ? 8 : Kb < 19 ? 32 : Kb < 77 ? 128 : Kb < 307 ? 512 : 2048) - 1;
     subg = cand; subg.tab = L.tab[0];                                                                          // cand.copy(): likewise
     RF = 0;
