@@ -181,13 +181,23 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
                 __syncthreads();
                 if (__ballot(RM != 0)) { P &= ~RM; continue; }
                 if (__ballot(UN != 0)) { R |= UN; size += bs_count(UN); P &= ~UN; continue; }
-                const int pv = bs_first(PE);
-                if (pv >= 0) {
-                    const uint64_t row = (lane < nw) ? c.A[(int64_t)pv * c.as + lane] : 0ull;
-                    const uint64_t bv = bit_if(lane, pv);
-                    const int pu = bs_first(P & ~row & ~bv);           // its only conflict
-                    R |= bv; size++;
-                    P &= ~(bv | bit_if(lane, pu));
+                if (__ballot(PE != 0)) {
+                    // ALL the pendants of this pass, one after the other WITHOUT a new degree pass in between (round 4: one pendant per
+                    // pass made the degree pass - K x nw adjacency words - the cost of every sparse conflict graph): removing vertices
+                    // only lowers conflict degrees, so a pendant stays pendant (or becomes universal) whatever was taken before it; one
+                    // that left P meanwhile was another pendant's partner
+                    uint64_t PEc = PE;
+                    for (;;) {
+                        const int pv = bs_first(PEc);
+                        if (pv < 0) break;
+                        const uint64_t bv = bit_if(lane, pv);
+                        PEc &= ~bv;
+                        if (!__ballot((P & bv) != 0)) continue;
+                        const uint64_t row = (lane < nw) ? c.A[(int64_t)pv * c.as + lane] : 0ull;
+                        const int pu = bs_first(P & ~row & ~bv);       // its only conflict, if it is still there
+                        R |= bv; size++;
+                        P &= ~(bv | bit_if(lane, pu));
+                    }
                     continue;
                 }
                 key = wave_min_i(key);
