@@ -235,7 +235,9 @@ def _render_sequence(job):
 def render_sequences(seeds, frames, md, work, procs):
     """the rank's distinct synthetic sequences, rendered on host cores in parallel (input generation, before the GPU is touched)"""
     jobs = [(s, frames, md, work) for s in seeds]
-    procs = procs if procs > 0 else max(1, min(len(jobs), (os.cpu_count() or 2) // 2))
+    # (default: half the logical cores, shared between the ranks of the node - eight ranks rendering at once must not oversubscribe it)
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    procs = procs if procs > 0 else max(1, min(len(jobs), (os.cpu_count() or 2) // (2 * world)))
     if procs == 1 or len(jobs) == 1:
         return [_render_sequence(j) for j in jobs]
     import multiprocessing as mp
@@ -404,7 +406,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
 
     # per-step records are consumed INSIDE the timed loop, two steps behind the enqueue front (result ring: waiting for step
     # s - 2 does not drain steps s - 1 and s): every pose of every lane is read, retracks are counted as they happen
-    stat = dict(steps=0, retracks=0, tracked=0, good=0, inliers=0, overflow=0)
+    stat = dict(steps=0, retracks=0, tracked=0, good=0, inliers=0, overflow=0, unproven=0)
 
     def consume(step):
         if args.dry_engine or step < 0:
@@ -419,6 +421,9 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             if en is engs[0]:
                 stat.setdefault("per_step", {})[step] = nrt           # lanes of engine 0 that re-detected in this step
             stat["overflow"] += int(np.count_nonzero((r["flags"] >> 8) & 15))
+            # result flag bit 0 = the maximum clique is PROVEN maximum (clique.hip: the search stayed below its node limit; an empty
+            # problem counts as proven): anything else would be less work than the reference does inside the timed region
+            stat["unproven"] += int(np.count_nonzero((r["flags"] & 1) == 0))
             stat["tracked"] += int(r["n_tracked"].sum()); stat["good"] += int(r["n_good"].sum()); stat["inliers"] += int(r["n_inliers"].sum())
         retracks_per_step.append(tot)
 
@@ -580,6 +585,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
                        "retrack_fraction": round(stat["retracks"] / max(1, stat["steps"] * (B // max(1, len(engs)))), 4) if stat["steps"] else None,
                        "retracks_per_step": None if not rps else {"min": int(min(rps)), "mean": round(float(np.mean(rps)), 1), "max": int(max(rps))},
                        "detect_overflows": stat["overflow"],
+                       "clique_unproven": stat["unproven"],
                        "mean_lm_nfev": round(float(np.mean([r["lm_nfev"] for r in res])), 1),
                        "keyframe_broadcast_ms": None if kf_ms is None else round(kf_ms, 3)},
             "roofline": None, "cpu_baseline": None,

@@ -88,6 +88,7 @@ struct Engine {
     uint8_t *rmap = nullptr;
     int rmap_cap = 0;
     int64_t rmap_n = 0;                             // keyframes received so far (slot = index % rmap_cap)
+    int64_t rmap_n_bcast = 0;                       // ... of which through roam_bcast_keyframe (host-side appends; never mixed with the exchange)
     std::vector<int32_t> rmap_root;                 // sending rank of each slot
     // per-step keyframe exchange (roam_keyframe_exchange): fixed-size records, one all-gather per step on its own stream, the
     // received keyframes appended on the device - the host never waits
@@ -97,8 +98,10 @@ struct Engine {
     int64_t *rmap_n_dev = nullptr;                  // keyframes appended by the exchange (device-side count)
     int32_t *rmap_root_dev = nullptr;               // their sending ranks, per slot
     int64_t kfx_calls = 0;
+    bool kfx_ready = false;                         // every resource of the exchange exists (set last: a failed set-up is retried, never half used)
     hipStream_t st_comm = nullptr;
-    hipEvent_t ev_kfx = nullptr;
+    hipEvent_t ev_kfx[3] = {};                      // the PACK kernel of the exchange that read peak-ring slot i (the streams that overwrite its inputs wait for it)
+    int kfx_last = -1;                              // slot of the latest pack
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t ev_join = nullptr, ev_pk0 = nullptr, ev_pk1 = nullptr;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[4] = {}, ev_g4[4] = {};                // back-end milestones stage A of step N+3 waits for
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void kfx_pack_kernel(uint8_t *__restrict__ buf
 // record r depends on the valid records before it)
 __global__ __launch_bounds__(256) void kfx_append_kernel(const uint8_t *__restrict__ recv, int world, size_t rec_bytes,
                                                          uint8_t *__restrict__ rmap, size_t slot_bytes, int cap,
-                                                         int64_t *__restrict__ n_dev, int32_t *__restrict__ root_dev)
+                                                         int64_t *__restrict__ n_dev, int32_t *__restrict__ root_dev, int max_feat, int max_peaks)
 {
     __shared__ int64_t base;
     if (threadIdx.x == 0) base = *n_dev;
@@ -479,7 +482,8 @@ __global__ __launch_bounds__(256) void kfx_append_kernel(const uint8_t *__restri
         const uint8_t *src = recv + (size_t)r * rec_bytes;
         const roam_keyframe_hdr *h = reinterpret_cast<const roam_keyframe_hdr *>(src);
         const int n = h->n_features, P = h->n_peaks;
-        if (n < 0) continue;
+        if (n < 0) continue;                                                 // the rank made no keyframe in this step
+        if (n > max_feat || P < 0 || P > max_peaks) continue;               // (a record no pack kernel writes: never copied past a slot)
         uint8_t *dst = rmap + (size_t)(cnt % cap) * slot_bytes;
         const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
         uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
@@ -531,7 +535,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     if (e->results_host) hipHostFree(e->results_host);
     for (auto &ev : e->ev_res) if (ev) hipEventDestroy(ev);
     if (e->st_comm) { hipStreamSynchronize(e->st_comm); hipStreamDestroy(e->st_comm); }
-    if (e->ev_kfx) hipEventDestroy(e->ev_kfx);
+    for (auto &ev : e->ev_kfx) if (ev) hipEventDestroy(ev);
     if (e->ev_pool) hipEventDestroy(e->ev_pool);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
@@ -933,8 +937,10 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
         uint8_t *dst = e->rmap + (size_t)(e->rmap_n % e->rmap_cap) * slot_bytes;
         HIP_TRY(ctx, hipMemcpyAsync(dst, e->kfb, KFB_HDR + sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToDevice, st));
         if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(dst + KFB_PEAKS_OFF, e->kfb + KFB_PEAKS_OFF, (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+        if (e->kfx_calls) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
         e->rmap_root[e->rmap_n % e->rmap_cap] = root;
         e->rmap_n++;
+        e->rmap_n_bcast++;
     }
     if (locals_xy) {
         if (n > cap_pts) { ROAM_SET_ERR(ctx, "bcast_keyframe: %d features, capacity %d", n, cap_pts); return ROAM_E_CAPACITY; }
@@ -960,15 +966,21 @@ int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane)
     if (e->rmap_cap <= 0) { ROAM_SET_ERR(ctx, "keyframe_exchange: reserve the remote map first"); return ROAM_E_STATE; }
     if (e->nstep == 0) { ROAM_SET_ERR(ctx, "keyframe_exchange: no step enqueued"); return ROAM_E_STATE; }
     const int world = roam_comm_world(ctx);
-    if (!e->kfx_send) {
+    // (the append kernel writes the records of one gather into consecutive ring slots: fewer slots than ranks would tear them)
+    if (e->rmap_cap < world) { ROAM_SET_ERR(ctx, "keyframe_exchange: remote map of %d slots for %d ranks", e->rmap_cap, world); return ROAM_E_CAPACITY; }
+    if (e->rmap_n_bcast) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
+    if (!e->kfx_ready) {
         e->kfx_peaks = std::min(e->cfg.peaks_cap, 32768);
         e->kfx_rec = KFB_PEAKS_OFF + (size_t)e->kfx_peaks * 8;
-        if (!dalloc(ctx, e, &e->kfx_send, e->kfx_rec) || !dalloc(ctx, e, &e->kfx_recv, e->kfx_rec * (size_t)world) ||
-            !dalloc(ctx, e, &e->rmap_n_dev, 1) || !dalloc(ctx, e, &e->rmap_root_dev, (size_t)e->rmap_cap)) return ROAM_E_HIP;
+        if (!e->st_comm) HIP_TRY(ctx, hipStreamCreateWithFlags(&e->st_comm, hipStreamNonBlocking));
+        for (auto &ev : e->ev_kfx) if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (!e->kfx_send && !dalloc(ctx, e, &e->kfx_send, e->kfx_rec)) return ROAM_E_HIP;
+        if (!e->kfx_recv && !dalloc(ctx, e, &e->kfx_recv, e->kfx_rec * (size_t)world)) return ROAM_E_HIP;
+        if (!e->rmap_n_dev && !dalloc(ctx, e, &e->rmap_n_dev, 1)) return ROAM_E_HIP;
+        if (!e->rmap_root_dev && !dalloc(ctx, e, &e->rmap_root_dev, (size_t)e->rmap_cap)) return ROAM_E_HIP;
         HIP_TRY(ctx, hipMemsetAsync(e->rmap_n_dev, 0, sizeof(int64_t), ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&e->st_comm, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_kfx, hipEventDisableTiming));
+        e->kfx_ready = true;
     }
     hipStream_t st = e->st_comm;
     const int rs = (int)((e->nstep - 1) % RES_RING);
@@ -978,12 +990,13 @@ int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane)
     HIP_TRY(ctx, hipGetLastError());
     // the following steps overwrite what the pack kernel reads (keyframe state: the compute stream; the peak list of this ring slot:
     // the peak stream, three steps on): their streams wait for the PACK, not for the collective
-    HIP_TRY(ctx, hipEventRecord(e->ev_kfx, st));
+    HIP_TRY(ctx, hipEventRecord(e->ev_kfx[e->pk], st));
+    e->kfx_last = e->pk;
     int32_t rc = roam_comm_allgather_bytes(ctx, e->kfx_send, e->kfx_recv, e->kfx_rec, st);
     if (rc != ROAM_OK) return rc;
     const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
     hipLaunchKernelGGL(kfx_append_kernel, dim3(1), dim3(256), 0, st, e->kfx_recv, world, e->kfx_rec, e->rmap, slot_bytes, e->rmap_cap,
-                       e->rmap_n_dev, e->rmap_root_dev);
+                       e->rmap_n_dev, e->rmap_root_dev, KS, e->kfx_peaks);
     HIP_TRY(ctx, hipGetLastError());
     e->kfx_calls++;
     return ROAM_OK;
@@ -992,11 +1005,11 @@ int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane)
 // the exchange stream has drained: pull the device-side count and senders over to the host's bookkeeping
 static int32_t kfx_settle(roam_ctx *ctx, Engine *e)
 {
-    if (!e->kfx_send) return ROAM_OK;
+    if (!e->kfx_ready) return ROAM_OK;
     HIP_TRY(ctx, hipStreamSynchronize(e->st_comm));
     int64_t n = 0;
     HIP_TRY(ctx, hipMemcpy(&n, e->rmap_n_dev, sizeof(n), hipMemcpyDeviceToHost));
-    if (n > 0 && e->rmap_n > 0 && e->rmap_n != n) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
+    // (the map may be polled while the loop runs: the device-side count only grows; the two producers refuse each other at call time)
     if (n > 0) {
         e->rmap_n = n;
         HIP_TRY(ctx, hipMemcpy(e->rmap_root.data(), e->rmap_root_dev, sizeof(int32_t) * (size_t)e->rmap_cap, hipMemcpyDeviceToHost));
@@ -1122,9 +1135,12 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     //   A(N) waits for g4(N-3)   - that kernel reads the peak counts / scan indices of the same ring slot
     //   B(N) waits for A(N), KLT(N) waits for B(N)
     hipStream_t sA = ctx->stream2, sB = ctx->stream4;
-    if (e->kfx_calls) {                                     // a keyframe exchange is reading the previous step's keyframe / peak buffers
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e->ev_kfx, 0));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream5, e->ev_kfx, 0));
+    if (e->kfx_calls) {
+        // a keyframe exchange reads the previous step's keyframe state (the compute stream overwrites it: wait for the latest PACK) and the peak
+        // list of ITS ring slot, which the peak stream overwrites three steps later: stream5 waits for the pack that read the slot it is about
+        // to fill - not for the latest one, which would take the peak kernel out of the stage overlap
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, e->ev_kfx[e->kfx_last], 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream5, e->ev_kfx[(int)(e->nstep % 3)], 0));
     }
     const int rs = (int)(e->nstep % RES_RING);            // ring slot of this step's result records
     if (e->nstep >= RES_RING) HIP_TRY(ctx, hipEventSynchronize(e->ev_res[rs]));   // its previous copy (8 steps ago) has long landed

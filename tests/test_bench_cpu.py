@@ -51,6 +51,47 @@ def test_bench_under_torch_distributed_run_world2():
     _check(_line(r.stdout), 2, "torch.distributed.run env")
 
 
+def test_bench_under_torch_distributed_run_world8():
+    """the driver's 8-GPU command line, as it will be issued on an 8-GPU node (non-config5 default path), on the stub engine:
+    one JSON line from rank 0 with n_gpus 8, every rank seen by the collective, every rank's keyframe in every rank's map"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29651", BENCH, "--gpus", "8"] + ARGS, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(_line(r.stdout), 8, "torch.distributed.run env")
+
+
+def test_render_pool_is_shared_between_the_ranks_of_a_node(monkeypatch):
+    """eight ranks render their sequences at the same time: the default pool of a rank is cores / (2 * world), never cores / 2"""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = []
+
+    class FakePool:
+        def __init__(self, n):
+            seen.append(n)
+
+        def map(self, f, jobs):
+            return [None for _ in jobs]
+
+        def close(self):
+            pass
+
+        def join(self):
+            pass
+
+    class FakeCtx:
+        Pool = FakePool
+
+    import multiprocessing as mp
+    monkeypatch.setattr(mp, "get_context", lambda kind: FakeCtx)
+    monkeypatch.setattr(os, "cpu_count", lambda: 128)
+    for world, want in ((1, 16), (8, 8)):
+        monkeypatch.setenv("WORLD_SIZE", str(world))
+        bench.render_sequences(list(range(16)), 7, True, {}, 0)
+        assert seen[-1] == want, (world, seen)
+
+
 def test_launcher_ends_quickly_and_nonzero_when_a_rank_dies():
     """rank 1 raises in its second step while rank 0 is on its way into a barrier: the launcher notices the exit code, tells the
     survivor through the rendezvous directory, and returns non-zero within seconds - nobody waits out a 300 s rendezvous timeout

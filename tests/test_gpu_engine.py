@@ -385,6 +385,7 @@ def test_rccl_keyframe_exchange_in_the_loop_world1(sequences):
         eng.init_lane(0, 0, feat[:90], poses[0])
         comm = D.RcclComm(ctx, D.FileRendezvous(tempfile.mkdtemp(prefix="roam_rdv_"), 0, 1)) if exchange else None
         out, live = [], []
+        polls, mid_first = [], []
         try:
             if exchange:
                 eng.remote_map_reserve(16)
@@ -393,6 +394,11 @@ def test_rccl_keyframe_exchange_in_the_loop_world1(sequences):
                 eng.step([t])
                 if exchange:
                     eng.keyframe_exchange(0)
+                    if k in (len(order) // 3, 2 * len(order) // 3):       # the map is the loop's consumer API: polled WHILE the loop runs
+                        n_mid, res_mid = eng.remote_map_count()
+                        polls.append((k, n_mid))
+                        if res_mid:
+                            mid_first.append(eng.remote_map_get(0))
                 if exchange is False:                     # the reference run: read the keyframe a step leaves behind (blocking)
                     r = eng.results()[0]
                     live.append(eng.live_keyframe(0) if r["new_keyframe"] else None)
@@ -403,6 +409,11 @@ def test_rccl_keyframe_exchange_in_the_loop_world1(sequences):
                 n_rec, n_res = eng.remote_map_count()
                 got = [eng.remote_map_get(i) for i in range(n_res)]
                 assert n_rec == n_res
+                # the mid-run polls saw a growing prefix of the final map (kfx_settle used to refuse the second read)
+                assert [n for _, n in polls] == sorted(n for _, n in polls) and polls[-1][1] <= n_rec, polls
+                assert polls[-1][1] > 0 and n_rec > polls[0][1], (polls, n_rec)
+                for kf in mid_first:
+                    assert np.array_equal(kf["prunedUndistortedLocals"], got[0]["prunedUndistortedLocals"]) and kf["scan"] == got[0]["scan"]
         finally:
             if comm is not None:
                 comm.close()
