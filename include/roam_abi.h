@@ -294,6 +294,13 @@ int32_t roam_engine_kernel_chunk_ms(roam_ctx *ctx, const char *name, int32_t las
  * HIP events on the context stream; returns average ms per launch. */
 int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms,
                                 double *algo_bytes_per_launch);
+/* diagnostics of the device-side detector (getFeatures.py:39-51: integral image -> Hessian determinants -> 3 x 3 x 3 maxima): runs the
+ * image-scale kernels for n_slots detections (scratch slot i = the scan lane i % lanes stepped last) as two kernels (fused = 0: image in HBM)
+ * or as the fused kernel (fused = 1: image never leaves the CU) and returns, per slot, the candidate count and the first cap_per_slot
+ * candidates in (row, column, layer) order (rc = row << 16 | column << 2 | layer, val = determinant); S_out (optional, W x W float64) =
+ * the integral image of slot s_slot as that form computed it.  Needs retrack_on_device and one step; n_slots <= retrack_slots, lanes. */
+int32_t roam_engine_debug_detect(roam_ctx *ctx, int32_t fused, int32_t n_slots, int32_t cap_per_slot, uint32_t *rc_out, double *val_out,
+                                 int32_t *n_out, int32_t s_slot, double *S_out);
 
 /* ---- multi-GPU.  One process per GPU, sequences sharded by rank, no data-path collective.  The only exchange
  * of the path is handing a keyframe to a global map (reference Mapping.Map.addKeyframe, Mapping.py:118-147; BASELINE

@@ -641,6 +641,20 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.boxtab), retrack_boxtab_words(e->W));
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.darktab), retrack_darktab_words(e->W));
         ok = ok && dalloc(ctx, e, &r.colT, (size_t)std::min(R, RT_TWO_PASS_SLOTS) * ((e->W + 63) / 64) * e->W);
+        // the fused detection kernel (retrack_fused.inc: integral image + determinants + maxima without the float64 image in HBM) serves
+        // chunks of >= RT_TWO_PASS_SLOTS detections when ROAM_FUSED_DETECT=1 asks for it.  It is bit-identical to the two-kernel form
+        // (tests/test_gpu_fused_detect.py) and MEASURED SLOWER - 27 ms against 12.6 ms per 512 detections, DESIGN.md section 6e: the path is
+        // bound by instruction issue, not by HBM - so the two-kernel form stays the default.  Its tables: transposed sampling map,
+        // footprints and dark steps per band; per slot: two hand-off buffers + the column totals
+        {
+            const char *fv = getenv("ROAM_FUSED_DETECT");
+            r.fused = (fv && fv[0] == '1') ? 1 : 0;
+            r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
+            ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.fd_mapT), npx);
+            ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.fd_boxtab), retrack_fused_boxtab_words(e->W));
+            ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.fd_darktab), retrack_darktab_words(e->W));
+            ok = ok && dalloc(ctx, e, &r.fd_halo, (size_t)R * 2 * (size_t)r.fd_halo_words) && dalloc(ctx, e, &r.fd_cc, (size_t)R * 2048);
+        }
         // candidate lists and bookkeeping tables per DETECTION (0.9 MB each): K4-K7 run once per step over all of them
         const size_t D = (size_t)B;
         ok = ok && dalloc(ctx, e, &r.cand_rc, D * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_val, D * BP_MAX_PTS) && dalloc(ctx, e, &r.cand_n, D);
@@ -691,6 +705,8 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     HIP_TRY(ctx, launch_pyr_dark(ctx->stream, e->warp_map, e->W, e->W, cfg->clip, e->pyr_dark));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_boxtab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.boxtab)));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_darktab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.darktab)));
+    if (e->rt_on) HIP_TRY(ctx, launch_retrack_fused_tables(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.fd_mapT),
+                                                           const_cast<uint32_t *>(e->rt.fd_boxtab), const_cast<uint32_t *>(e->rt.fd_darktab)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
 }
@@ -1465,10 +1481,11 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             hipError_t er = launch_peaks(st, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[(e->pk + 1) % 3], c.peaks_cap, e->peaks_n[(e->pk + 1) % 3]);
             HIP_TRY(ctx, er);
             bytes = (double)B * ((double)c.rows * c.clip);
-        } else if (!strcmp(name, "doh_integral") || !strcmp(name, "doh_det_maxima")) {
+        } else if (!strcmp(name, "doh_integral") || !strcmp(name, "doh_det_maxima") || !strncmp(name, "doh_fused", 9)) {
             // the image-scale kernels of the device-side retrack over all scratch slots (per launch: `slots` detections)
             if (!e->rt_on) { hipEventDestroy(a); hipEventDestroy(b); ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
-            const int P = e->rt.slots, which = !strcmp(name, "doh_integral") ? 0 : 1;
+            // ("doh_fused:<d>": with diagnostics word d - ablations of retrack_fused.inc, measurement only)
+            const int P = e->rt.slots, which = !strcmp(name, "doh_integral") ? 0 : (!strcmp(name, "doh_det_maxima") ? 1 : 2 + (name[9] == ':' ? atoi(name + 10) : 0));
             if (r == 0) {
                 std::vector<int32_t> sc(P);
                 for (int i = 0; i < P; i++) sc[i] = e->last_scan[i % B] >= 0 ? e->last_scan[i % B] : 0;
@@ -1479,12 +1496,14 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
                 HIP_TRY(ctx, hipEventRecord(a, st));
             }
             HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, which));
+            if (which >= 1) HIP_TRY(ctx, hipMemsetAsync(e->rt.cand_n, 0, sizeof(int32_t) * (size_t)P, st));   // (no bookkeeping follows that would clear the counts)
             const double npx = (double)e->W * e->W;
             // algorithmic bytes per detection (strict): integral image = polar payload read + float64 image written once
             // (the 4-byte sampling-map word per pixel it also reads is the same geometry table for every detection and mostly comes
             // out of L2: not input data, not counted since round 4); determinants + maxima = float64 image read once (the
             // candidates it writes are a few KB)
-            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 8.0) : npx * 8.0);
+            // the fused kernel: the polar payload is all a detection reads; the float64 image never leaves the CU
+            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 8.0) : (which == 1 ? npx * 8.0 : (double)c.rows * c.clip));
         } else if (!strcmp(name, "pyramid")) {
             HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B, e->pyr_dark));
             double rd = 0, wr = 0;
@@ -1503,6 +1522,42 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
     hipEventDestroy(a); hipEventDestroy(b);
     *avg_ms = ms / reps;
     if (algo_bytes) *algo_bytes = bytes;
+    return ROAM_OK;
+}
+
+// diagnostics: the image-scale detection kernels of `n_slots` detections (scratch slot i works on the scan lane i % lanes saw last) in the
+// two-kernel form (fused = 0: rt_integral_kernel + rt_det_strip_kernel) or as rt_fused_kernel (fused = 1), candidates sorted into
+// (row, column, layer) order.  Out: per slot the count (cand_n, may exceed cap_per_slot) and the first cap_per_slot candidates; S_out
+// (optional, W x W doubles): the integral image of slot `s_slot` as that form computed it.  The parity tests hold the two forms equal.
+int32_t roam_engine_debug_detect(roam_ctx *ctx, int32_t fused, int32_t n_slots, int32_t cap_per_slot, uint32_t *rc_out, double *val_out,
+                                 int32_t *n_out, int32_t s_slot, double *S_out)
+{
+    ENGINE();
+    ARG_CHECK(ctx, n_slots >= 1 && cap_per_slot >= 0 && n_out);
+    if (!e->rt_on || !e->stepped) { ROAM_SET_ERR(ctx, "debug_detect: needs retrack_on_device and one step"); return ROAM_E_STATE; }
+    ARG_CHECK(ctx, n_slots <= e->rt.slots && n_slots <= e->B && (!S_out || (s_slot >= 0 && s_slot < n_slots)));
+    hipStream_t st = ctx->stream;
+    const int P = n_slots, B = e->B;
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::vector<int32_t> sc(P);
+    for (int i = 0; i < P; i++) sc[i] = e->last_scan[i % B] >= 0 ? e->last_scan[i % B] : 0;
+    HIP_TRY(ctx, hipMemcpy(e->rt.rt_scan, sc.data(), sizeof(int32_t) * (size_t)P, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(e->rt.rt_n, &P, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemsetAsync(e->rt.cand_n, 0, sizeof(int32_t) * (size_t)P, st));
+    if (fused) HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, S_out ? 3 : 2));
+    else { HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, 0)); HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, 1)); }
+    HIP_TRY(ctx, launch_retrack_emit(st, e->rt, P));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipMemcpy(n_out, e->rt.cand_n, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost));
+    const int keep = std::min(cap_per_slot, BP_MAX_PTS);
+    for (int i = 0; i < P && keep > 0; i++) {
+        if (rc_out) HIP_TRY(ctx, hipMemcpy(rc_out + (size_t)i * cap_per_slot, e->rt.cand_rc + (size_t)i * BP_MAX_PTS, sizeof(uint32_t) * (size_t)keep, hipMemcpyDeviceToHost));
+        if (val_out) HIP_TRY(ctx, hipMemcpy(val_out + (size_t)i * cap_per_slot, e->rt.cand_val + (size_t)i * BP_MAX_PTS, sizeof(double) * (size_t)keep, hipMemcpyDeviceToHost));
+    }
+    if (S_out)
+        HIP_TRY(ctx, hipMemcpy2D(S_out, sizeof(double) * (size_t)e->W, e->rt.S + (size_t)s_slot * e->rt.SP * e->W, sizeof(double) * (size_t)e->rt.SP,
+                                 sizeof(double) * (size_t)e->W, (size_t)e->W, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(e->rt.cand_n, 0, sizeof(int32_t) * (size_t)P));     // the lists are clean for the next detection
     return ROAM_OK;
 }
 

@@ -42,6 +42,14 @@ struct RtArgs {
     int32_t *kp_n, *slot_flags;
     int32_t *ssc_work;              // 4 x BP_MAX_PTS
     int32_t *sel, *sel_n;           // BP_MAX_PTS, 1
+    // fused detection kernel (retrack_fused.inc: integral image + determinants + maxima in one kernel, chunks of >= RT_TWO_PASS_SLOTS detections)
+    int fused;                      // 1: rt_fused_kernel serves those chunks, rt_integral_kernel / rt_det_strip_kernel return at once for them
+    const uint32_t *fd_mapT;        // the sampling map transposed (W x W)
+    const uint32_t *fd_boxtab;      // polar footprint per (band + 1, block): retrack_fused_boxtab_words(W) words
+    const uint32_t *fd_darktab;     // per band: the dark steps (the format of darktab, made from the transposed map)
+    double *fd_halo;                // per slot: two hand-off buffers of fd_halo_words doubles (the 32 rows a band leaves to the band below)
+    int64_t fd_halo_words;
+    double *fd_cc;                  // per slot: 2048 column totals of the bands above
 };
 
 hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, const int32_t *scan_idx, int B, int force_all, const RtArgs &a);
@@ -53,11 +61,19 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
 hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride, const int32_t *count, int kp_cap, int P,
                             int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
                             const int32_t *n_active, int first);
+// which: 0 = integral image, 1 = determinants + maxima (both: the two-kernel form, whatever a.fused says), 2 + d = the fused kernel with
+// diagnostics word d (0 = none; bit 0: its integral image is written to a.S as well; higher bits: ablations, retrack_fused.inc)
 hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which);
+// candidates of the first P slots sorted into (row, column, layer) order (diagnostics: the lists stay as they are)
+hipError_t launch_retrack_emit(hipStream_t st, const RtArgs &a, int P);
 hipError_t retrack_init();
 // fills boxtab (retrack_boxtab_words(W) uint32 words) from the sampling map: geometry only, once per engine
 size_t retrack_boxtab_words(int W);
 hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *boxtab);
 // fills darktab (retrack_darktab_words(W) zero-initialised uint32 words) from the sampling map: geometry only, once per engine
 size_t retrack_darktab_words(int W);
+// tables of the fused kernel: transposed map (W * W words), footprints, dark steps per band
+size_t retrack_fused_boxtab_words(int W);
+size_t retrack_fused_halo_words(int W);
+hipError_t launch_retrack_fused_tables(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *mapT, uint32_t *boxtab, uint32_t *darktab);
 hipError_t launch_retrack_darktab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *darktab);

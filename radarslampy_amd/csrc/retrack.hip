@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 {
     extern __shared__ double ri_lds[];
     const int ls = blockIdx.x, slot = first + ls;
-    if (slot >= *a.rt_n || !rt_one_sweep(a, first)) return;
+    if (slot >= *a.rt_n || !rt_one_sweep(a, first) || a.fused) return;
     typedef double Tile[RI_ROWS][65];
     Tile *tiles = reinterpret_cast<Tile *>(ri_lds);                        // [2][RI_WAVES]
     const int W = a.W, H = a.W, t = threadIdx.x, wave = t >> 6, lane = t & 63;
@@ -738,6 +738,7 @@ template <int P> struct SdTag { static constexpr int value = P; };
 __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int first, int P, int nstrips)
 {
     const int nact = min(P, max(0, *a.rt_n - first));
+    if (a.fused && rt_one_sweep(a, first)) return;                          // rt_fused_kernel's chunk
     // XCD-aware order: workgroup id -> (XCD = id % 8, j = id / 8); XCD x owns the x-th contiguous eighth of the (detection, strip) list
     const int total = nact * nstrips, per = (total + 7) >> 3;
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
@@ -926,6 +927,8 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
     }
     maxima(te - 1, (te - 1) & 1);
 }
+
+#include "retrack_fused.inc"
 
 // ------------------------------------------------------------------------------------------------ K4: ordered candidates
 // the candidates of a detection (at most BP_MAX_PTS are kept) sorted by (row, column, layer): keys are unique, so a key's rank is
@@ -1294,8 +1297,21 @@ hipError_t launch_retrack_darktab(hipStream_t st, const uint32_t *map, int W, in
     return hipGetLastError();
 }
 
+size_t retrack_fused_boxtab_words(int W) { return 2 * (size_t)((W + SD_OUT - 1) / SD_OUT + 1) * (size_t)((W + SD_T - 1) / SD_T); }
+size_t retrack_fused_halo_words(int W) { return (size_t)((W + SD_T - 1) / SD_T) * SD_T * FD_HALO; }
+
+hipError_t launch_retrack_fused_tables(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *mapT, uint32_t *boxtab, uint32_t *darktab)
+{
+    const int nband = (W + SD_OUT - 1) / SD_OUT, nblk = (W + SD_T - 1) / SD_T;
+    hipLaunchKernelGGL(rf_mapT_kernel, dim3((W + 31) / 32, (W + 31) / 32), dim3(256), 0, st, map, W, mapT);
+    hipLaunchKernelGGL(rf_boxtab_kernel, dim3(nblk, nband + 1), dim3(64), 0, st, mapT, W, cols, nblk, boxtab);
+    // the dark steps of a band = the dark steps of a strip of the transposed image: rt_darktab_kernel on the transposed map
+    return launch_retrack_darktab(st, mapT, W, cols, darktab);
+}
+
 hipError_t retrack_init()
 {
+    if (hipError_t ef = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FD_LDS_BYTES); ef != hipSuccess) return ef;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_det_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS_BYTES);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(rt_integral_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RI_LDS_BYTES);
@@ -1324,7 +1340,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         const bool tr = trace && first / R < ntrace;
         hipEvent_t *tev = trace + 3 * (first / R);
         if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
-        if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
+        if (W <= 2048 && a.fused) hipLaunchKernelGGL(rt_fused_kernel, dim3(P), dim3(FD_THREADS), FD_LDS_BYTES, st, a, first, 0);
+        else if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
         if ((e = hipGetLastError()) != hipSuccess) return e;              // (a refused launch - LDS attribute, grid - surfaces here, not after the chain)
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
@@ -1353,9 +1370,22 @@ hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, c
 
 // measurement: re-run the image-scale kernels of the detection for the first `P` scratch slots (their integral images are
 // those of the last retracks; rt_n is set by the caller); which: 0 = integral image (cols + rows), 1 = determinants + maxima
-hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which)
+hipError_t launch_retrack_emit(hipStream_t st, const RtArgs &a, int P)
 {
+    hipLaunchKernelGGL(rt_emit_kernel, dim3(P), dim3(256), 0, st, a, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a_in, int P, int which)
+{
+    RtArgs a = a_in;
+    a.fused = which >= 2 ? 1 : 0;                                          // 0 / 1 time and check the two-kernel form whatever the engine runs
     const int W = a.W;
+    if (which >= 2) {
+        if (!a.fd_mapT) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(rt_fused_kernel, dim3(P), dim3(FD_THREADS), FD_LDS_BYTES, st, a, 0, which - 2);
+        return hipGetLastError();
+    }
     if (which == 0) {
         hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
@@ -1363,9 +1393,7 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a, int P, int which
         hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, 0);
     } else {
-        hipError_t e = launch_det(st, a, 0, P);
-        if (e != hipSuccess) return e;
-        return hipMemsetAsync(a.cand_n, 0, sizeof(int32_t) * (size_t)P, st);   // (no bookkeeping follows that would clear the counts)
+        return launch_det(st, a, 0, P);                                     // (the caller clears the candidate counts: no bookkeeping follows that would)
     }
     return hipGetLastError();
 }

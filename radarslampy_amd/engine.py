@@ -236,6 +236,18 @@ class Engine:
                                                             buf.size, C.byref(nc), C.byref(ns)))
         return buf[: ns.value * nc.value].reshape(ns.value, nc.value)
 
+    def debug_detect(self, fused: bool, n_slots: int, cap: int = 2048, s_slot: int = None):
+        """diagnostics (roam_engine_debug_detect): candidate lists of n_slots detections from the two-kernel form or the fused kernel;
+        returns (counts (n,), rc (n, cap) uint32, val (n, cap) float64[, S (W, W) float64 of slot s_slot])"""
+        n = np.zeros(n_slots, np.int32)
+        rc = np.zeros((n_slots, cap), np.uint32)
+        val = np.zeros((n_slots, cap), np.float64)
+        W = 2 * (self.cfg.clip // 2)
+        S = np.zeros((W, W), np.float64) if s_slot is not None else None
+        self.ctx.check(self.lib.roam_engine_debug_detect(self.ctx.h, int(bool(fused)), int(n_slots), int(cap), _ffi._ptr(rc), _ffi._ptr(val),
+                                                         _ffi._ptr(n), int(s_slot or 0), _ffi._ptr(S) if S is not None else None))
+        return (n, rc, val) if S is None else (n, rc, val, S)
+
     def time_kernel(self, name: str, reps: int = 20):
         ms = C.c_float(0)
         by = C.c_double(0)
