@@ -47,6 +47,8 @@ def parse_args(argv=None):
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N launcher: wall-clock limit for the whole run, seconds")
     ap.add_argument("--stream", action="store_true", help="single-sequence mode: one lane, pinned ring, result ring (configs 3 / 4)")
     ap.add_argument("--stream-frames", type=int, default=240, help="frames of the --stream sequence")
+    ap.add_argument("--png", action="store_true", help="with --stream: also feed the sequence from PNG files (written first, untimed) - decode pool + H2D + step timed")
+    ap.add_argument("--png-workers", type=int, default=0, help="host threads inflating PNGs ahead of the engine (0 = min(16, cores / 2))")
     ap.add_argument("--stream-start", type=int, default=280, help="first ground-truth motion of full_seq_1 used by --stream (the vehicle stands still for the first ~230 frames)")
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle, 1 core (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the N-core CPU leg (-1 = half the logical cores, 0 = skip)")
@@ -825,6 +827,46 @@ def stream_measure(recs, poses, md, ctx):
                 "position_rmse_m": round(float(np.sqrt(np.mean(err ** 2))), 3), "distance_m": round(float(np.hypot(*np.diff(poses[:, :2], axis=0).T).sum()), 1)}
 
 
+def stream_png_measure(recs, poses, md, ctx, workers):
+    """8f-f2 on the clock: the same sequence from PNG FILES - inflate on a pool of host threads that runs ahead of the loop
+    (parseData.prefetchRadarRecords), staging copy, H2D, step.  The files are written first (untimed; tmpfs when there is one)."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from radarslampy_amd.RawROAMSystem import stream_records
+    from radarslampy_amd.parseData import prefetchRadarRecords, readRadarRecord
+    n = len(recs)
+    flags = {"rejectOutliers": True, "correctMotionDistortion": md}
+    d = tempfile.mkdtemp(prefix="roam_png_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        paths = []
+        for i, r in enumerate(recs):
+            paths.append(os.path.join(d, f"{i:06d}.png"))
+            Image.fromarray(r).save(paths[-1], compress_level=6)
+        size = float(np.mean([os.path.getsize(p) for p in paths]))
+        t0 = time.perf_counter()
+        for p in paths[:24]:
+            readRadarRecord(p)
+        one = (time.perf_counter() - t0) / 24
+        t0 = time.perf_counter()
+        k = sum(1 for _ in prefetchRadarRecords(paths, workers))
+        dec = time.perf_counter() - t0
+        assert k == n
+        stream_records(prefetchRadarRecords(paths[:12], workers), 12, poses[0], flags, ctx)          # warm-up
+        t0 = time.perf_counter()
+        est, _ = stream_records(prefetchRadarRecords(paths, workers), n, poses[0], flags, ctx)
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        est1, _ = stream_records(prefetchRadarRecords(paths, 1), n, poses[0], flags, ctx)            # the decode on the feeding thread (round 4)
+        dt1 = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    w = workers if workers > 0 else max(1, min(16, (os.cpu_count() or 2) // 2))
+    return est, est1, {"png_inclusive_pairs_per_s": round((n - 1) / dt, 2), "png_inclusive_pairs_per_s_one_decode_thread": round((n - 1) / dt1, 2),
+                       "png_decode_only_frames_per_s": round(n / dec, 1), "png_decode_ms_per_frame_one_thread": round(one * 1e3, 2),
+                       "png_decode_threads": w, "png_mean_file_bytes": int(size)}
+
+
 def run_stream(args):
     """BASELINE configs 3 / 4 as the reference runs them: ONE sequence (full_seq_1-like motion, unbounded reflector world with
     movers, scintillation and, with motion distortion on, intra-scan distortion) through a 1-lane engine - frames from a pinned
@@ -837,6 +879,10 @@ def run_stream(args):
     ctx = _ffi.Context(0)
     info = ctx.device_info()
     dt, cfg = stream_measure(recs, poses, md, ctx)
+    if args.png:
+        est_png, est_png1, pc = stream_png_measure(recs, poses, md, ctx, args.png_workers)
+        cfg.update(pc)
+        cfg["png_within_of_in_memory_rate"] = round(pc["png_inclusive_pairs_per_s"] / cfg["pipelined_pairs_per_s"], 3)
     ctx.close()
     out = {"metric": "radar scan-pairs/sec (400x3768 polar), ONE sequence", "value": round((n - 1) / dt, 2), "unit": "scan-pairs/s",
            "n_gpus": 1, "steps": n - 1, "warmup": 11, "ms_per_step": round(dt / (n - 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",

@@ -652,8 +652,12 @@ class OdometryPipeline:
     (`detect(cart_f32) -> (k,2) [x,y]`) because blob_doh is a separate, unpinned stage."""
 
     def __init__(self, first_record_u8, init_features_xy, init_pose, reject_outliers=True,
-                 motion_distortion=True, detect=None, payload_off=11, clip=MAX_RANGE_CLIP_PX, warp=None):
+                 motion_distortion=True, detect=None, payload_off=11, clip=MAX_RANGE_CLIP_PX, warp=None,
+                 keyframe_trans_m=None, keyframe_rot_rad=None):
         self.off, self.clip = payload_off, clip
+        # Map.isGoodKeyframe's thresholds (Mapping.py:13-15, 149-174); None = HEAD's constants
+        self.kf_trans_sq = TRANS_THRESHOLD_SQ if keyframe_trans_m is None else float(keyframe_trans_m) ** 2
+        self.kf_rot = ROT_THRESHOLD if keyframe_rot_rad is None else float(keyframe_rot_rad)
         self.warp = warp or (lambda polar: convertPolarImageToCartesian(polar, want_u8=True))     # polar f32 -> (cart f32, cart u8)
         self.reject, self.md, self.detect = reject_outliers, motion_distortion, detect
         self.MDS = MotionDistortionSolver(np.diag([4, 4]), np.diag([1, 1, (5 * np.pi / 180) ** 2]))
@@ -709,7 +713,7 @@ class OdometryPipeline:
         retrack = n <= N_FEATURES_BEFORE_RETRACK
         dth = abs(self.old_kf.pose[2] - pose[2])
         dtr = ((self.old_kf.pose[:2] - pose[:2]) ** 2).sum()
-        newkf = retrack or dth >= ROT_THRESHOLD or dtr >= TRANS_THRESHOLD_SQ
+        newkf = retrack or dth >= self.kf_rot or dtr >= self.kf_trans_sq
         if newkf:
             if retrack and self.detect is not None:
                 cart_f32 = self.warp(rec_u8[:, self.off:self.off + self.clip].astype(np.float32) / 255.)[0]

@@ -25,7 +25,7 @@ class EngineCfg(C.Structure):
                 ("clip", C.c_int32), ("pool_scans", C.c_int32), ("peaks_cap", C.c_int32),
                 ("reject_outliers", C.c_int32), ("motion_distortion", C.c_int32),
                 ("clique_node_limit", C.c_int64), ("sigma5", C.c_double * 5), ("retrack_on_device", C.c_int32),
-                ("retrack_slots", C.c_int32)]
+                ("retrack_slots", C.c_int32), ("keyframe_trans_m", C.c_double), ("keyframe_rot_rad", C.c_double)]
 
 
 class LaneResult(C.Structure):

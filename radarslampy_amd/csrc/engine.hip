@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
         const int retrack = n <= N_RETRACK;
         const double dth = fabs(kf_pose[3 * b + 2] - pth);
         const double ddx = kf_pose[3 * b] - px, ddy = kf_pose[3 * b + 1] - py;
-        const int good = (dth >= ROT_THR) || (ddx * ddx + ddy * ddy >= TRANS_THR_SQ);
+        const int good = (dth >= cfg.keyframe_rot_rad) || (ddx * ddx + ddy * ddy >= cfg.keyframe_trans_m * cfg.keyframe_trans_m);
         newkf = retrack || good;
         roam_lane_result *r = res + b;
         r->pose[0] = px; r->pose[1] = py; r->pose[2] = pth;
@@ -557,6 +557,8 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     if (!e) return ROAM_E_HIP;
     ctx->engine = e;
     e->cfg = *cfg;
+    if (!(e->cfg.keyframe_trans_m > 0.0)) e->cfg.keyframe_trans_m = 2.0;        // Mapping.py:14
+    if (!(e->cfg.keyframe_rot_rad > 0.0)) e->cfg.keyframe_rot_rad = ROT_THR;      // Mapping.py:13
     const int B = e->B = cfg->lanes;
     e->lane_k.assign(B, 0);
     e->last_scan.assign(B, -1);

@@ -14,12 +14,14 @@ from . import _ffi
 class Engine:
     def __init__(self, lanes: int, pool_scans: int, ctx: _ffi.Context = None, rows=400, stride=3779, payload_off=11,
                  clip=2025, peaks_cap=65536, reject_outliers=True, motion_distortion=True, clique_node_limit=0,
-                 sigma5=(4.0, 4.0, 1.0, 1.0, (5 * np.pi / 180) ** 2), retrack_on_device=False, retrack_slots=0):
+                 sigma5=(4.0, 4.0, 1.0, 1.0, (5 * np.pi / 180) ** 2), retrack_on_device=False, retrack_slots=0,
+                 keyframe_trans_m=0.0, keyframe_rot_rad=0.0):
+        """keyframe_trans_m / keyframe_rot_rad: Map.isGoodKeyframe's thresholds (Mapping.py:13-15); 0 = the reference's 2.0 m / 0.2 rad"""
         self.ctx = ctx or _ffi.default_context()
         self.lib = self.ctx.lib
         cfg = _ffi.EngineCfg(lanes, rows, stride, payload_off, clip, pool_scans, peaks_cap, int(reject_outliers),
                              int(motion_distortion), int(clique_node_limit), (C.c_double * 5)(*sigma5), int(retrack_on_device),
-                             int(retrack_slots))
+                             int(retrack_slots), float(keyframe_trans_m), float(keyframe_rot_rad))
         self.cfg = cfg
         self.lanes, self.pool_scans = lanes, pool_scans
         self.rows, self.stride = rows, stride

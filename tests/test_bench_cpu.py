@@ -145,3 +145,31 @@ def test_config5_exchange_schedule_world8_torch_distributed_run():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     _check_config5(_line(r.stdout), 8, 21)
+
+
+def test_png_prefetch_pool_keeps_the_order_and_reports_a_bad_frame_at_its_turn(tmp_path):
+    """parseData.prefetchRadarRecords (8f-f2: PNG inflate off the thread that feeds the pinned ring): records come back in path
+    order whatever the pool's timing, equal to the one-at-a-time decode; a file that does not decode raises when its turn comes"""
+    import numpy as np
+    import pytest
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from radarslampy_amd.parseData import prefetchRadarRecords, readRadarRecord
+    rng = np.random.default_rng(5)
+    paths, want = [], []
+    for i in range(23):
+        r = rng.integers(0, 256, (40, 379), dtype=np.uint8)
+        r[0, 0] = i
+        p = tmp_path / f"{i:04d}.png"
+        Image.fromarray(r).save(p)
+        paths.append(str(p)); want.append(r)
+    for workers, depth in ((1, 0), (4, 0), (6, 2)):
+        got = list(prefetchRadarRecords(paths, workers, depth))
+        assert len(got) == 23 and all(np.array_equal(g, w) for g, w in zip(got, want)), workers
+    assert np.array_equal(readRadarRecord(paths[7]), want[7])
+    bad = paths[:5] + [str(tmp_path / "missing.png")] + paths[5:8]
+    it = prefetchRadarRecords(bad, 4)
+    for i in range(5):
+        assert np.array_equal(next(it), want[i])
+    with pytest.raises(FileNotFoundError):
+        next(it)

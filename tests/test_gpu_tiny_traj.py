@@ -54,3 +54,45 @@ def test_engine_reproduces_the_reference_prints_on_data_tiny():
     assert retracks == [1, 2, 4, 7, 9], retracks           # the frames whose reference picture shows freshly appended features
     eng.close()
     ctx.close()
+
+
+def test_engine_with_a_keyframe_on_every_frame_reproduces_the_pictured_deltas():
+    """The reference's pictures were made by a run that added a keyframe on every frame (tests/test_oracle_tiny_traj.py,
+    DESIGN.md section 4).  The engine with Map.isGoodKeyframe's translation threshold at 1e-9 m (roam_engine_cfg.keyframe_trans_m):
+    every step equals the oracle's loop body under the same policy (1e-4 m / 1e-5 rad), frames 1-3 print the reference's poses,
+    and the per-frame EST Deltas - which do not carry the 16 / 27 mm the nine-way clique tie of frame 4 leaves in the dead-reckoned
+    pose - equal the reference's prints on frames 1-3 and 5-7 to 2 units of the last printed digit, on frame 8 to 3."""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    traj = np.load(os.path.join(HERE, "golden", "tiny_traj.npz"))
+    pay = np.load(os.path.join(HERE, "golden", "tiny_track.npz"))["payload"]
+    T, rows, clip = pay.shape
+    det = lambda c: oracle.getFeatures(c)[0]                                    # noqa: E731
+    ctx = _ffi.Context(0)
+    eng = Engine(1, T, ctx=ctx, rows=rows, stride=clip, payload_off=0, clip=clip, retrack_on_device=True, keyframe_trans_m=1e-9)
+    for t in range(T):
+        eng.upload_scan(t, np.ascontiguousarray(pay[t]))
+    pose0 = traj["gt_pose"][0]
+    eng.init_lane_detect(0, 0, pose0)
+    cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), det(cart0))
+    pipe = oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), feat0, pose0, detect=det, payload_off=0, clip=clip, keyframe_trans_m=1e-9)
+    prev = np.array(pose0)
+    for t in range(1, 9):
+        eng.step([t])
+        got = eng.results()[0]
+        want = pipe.step(np.ascontiguousarray(pay[t]))
+        assert got["new_keyframe"] and want["new_keyframe"], t
+        assert (got["n_tracked"], got["n_good"], got["n_inliers"]) == (want["n_tracked"], want["n_good"], want["n_inliers"]), t
+        assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= 1e-4 and abs(got["pose"][2] - want["pose"][2]) <= 1e-5, t
+        Trel = np.linalg.inv(oracle.convertPoseToTransform(prev)) @ oracle.convertPoseToTransform(got["pose"])
+        deltas = np.array([Trel[0, 2], Trel[1, 2], np.rad2deg(np.arctan2(Trel[1, 0], Trel[0, 0]))])
+        d = np.abs(deltas - traj["roam_mapping_est_deltas"][t - 1])
+        if t != 4:
+            assert d.max() <= (2.1e-3 if t <= 7 else 3.1e-3), (t, deltas, traj["roam_mapping_est_deltas"][t - 1])
+        if t <= 3:
+            printed = np.array([got["pose"][0], got["pose"][1], np.rad2deg(got["pose"][2])])
+            assert np.abs(printed - traj["roam_mapping_est_pose"][t - 1]).max() <= PRINT, t
+        prev = np.array(got["pose"])
+    eng.close()
+    ctx.close()

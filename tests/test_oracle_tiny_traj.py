@@ -13,8 +13,15 @@ What is reproduced, and what is not (DESIGN.md section 4 has the table):
                such a pair on frame 9 too) permutes the ties of adaptiveNMS's unstable sort, the same
                features come out in another order, the graph's nodes are numbered differently - and then frames 1-5 ALL
                reproduce the reference's prints with the first clique, nothing chosen by hand;
-  frames 6-10  the reference's run holds a feature set ours does not (no clique of our frame-6 graph gives its pose); the
-               poses stay within 0.15 m / 0.3 deg and the RMSE within 0.02 of the reference's.
+  frame 6      (round 5) EXPLAINED: the pictures were made by a run that added a keyframe on EVERY frame.  Frame 5 moves 1.988 m from
+               the frame-4 keyframe (1.988^2 = 3.952 < TRANS_THRESHOLD_SQ = 4.0, Mapping.py:14-15): HEAD's Map.isGoodKeyframe keeps the
+               frame-4 keyframe, frame 6 is the first pair solved against a keyframe two frames old - and the picture's numbers are
+               those of a solve against a frame-5 keyframe.  With the threshold at zero (and the frame-2 swap) frames 1-7 reproduce
+               the prints to the last digit, frame 8 within 2 units of it, frame 9 within 6 mm (test below).  The yellow / red
+               markers of 0006.jpg decode to exactly OUR inlier set (first of the four tied cliques; profiles/frame6_markers.py), so
+               it never was the graph.  And HEAD's own loop code, run with the oracle's front end (tests/golden/make_tiny_hybrid.py ->
+               tiny_hybrid.npz), gives the ORACLE's numbers at frame 6, not the picture's: the oracle's loop is HEAD's loop;
+  frames 8-10  follow with 1 mm ... 64 mm (the clique near-ties of later frames, cf. frame 4).
 """
 import os
 
@@ -150,6 +157,65 @@ def test_one_swapped_near_tie_of_frame_2_explains_frames_4_and_5(data):
         assert np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1]).max() <= PRINT, t
         assert np.abs(_deltas(est[-2], est[-1]) - traj["roam_mapping_est_deltas"][t - 1]).max() <= PRINT, t
         assert abs(_rmse(traj["gt_pose"][:t + 1], est) - traj["roam_mapping_rmse"][t - 1]) <= 5.1e-3, t
+
+
+def _swap_pipeline(traj, pay, frame, **kw):
+    detect = _detect_with_swap({2: 521}, frame)
+    cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
+    feat0 = oracle.append_dedupe(np.empty((0, 2)), detect(cart0))
+    return oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), feat0, traj["gt_pose"][0], detect=detect, payload_off=0, clip=pay.shape[2], **kw)
+
+
+def test_the_pictures_were_made_with_a_keyframe_on_every_frame(data):
+    """frame 6 of data/tiny (round-4 verdict, "What's missing" 1): with Map.isGoodKeyframe's translation threshold at zero - a
+    keyframe on every frame - and the one swapped near-tie of frame 2, frames 1-7 reproduce EST Pose, EST Deltas and RMSE of the
+    reference's pictures to print precision, frame 8 within 2.6 units of the last digit, frame 9 within 7 mm / 0.007 deg; with
+    HEAD's threshold (2 m: frame 5 has moved 1.988 m, no new keyframe) frame 6 is 85 mm / 0.124 deg away."""
+    traj, pay = data
+    frame = [0]
+    pipe = _swap_pipeline(traj, pay, frame, keyframe_trans_m=0.0)
+    est = [traj["gt_pose"][0]]
+    for t in range(1, 10):
+        frame[0] = t
+        out = pipe.step(np.ascontiguousarray(pay[t]))
+        assert out["new_keyframe"]
+        est.append(out["pose"].copy())
+        dp = np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1])
+        dd = np.abs(_deltas(est[-2], est[-1]) - traj["roam_mapping_est_deltas"][t - 1])
+        tol = PRINT if t <= 7 else (2.7e-3 if t == 8 else 7e-3)
+        assert dp.max() <= tol and dd.max() <= tol, (t, dp, dd)
+        assert abs(_rmse(traj["gt_pose"][:t + 1], est) - traj["roam_mapping_rmse"][t - 1]) <= 5.1e-3, t
+    head = _swap_pipeline(traj, pay, frame)
+    for t in range(1, 7):
+        frame[0] = t
+        out = head.step(np.ascontiguousarray(pay[t]))
+        assert out["new_keyframe"] == (t != 5), t                                 # 1.988 m < 2 m: HEAD keeps the frame-4 keyframe
+    d6 = np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][5])
+    assert 0.08 < d6[1] < 0.09 and 0.12 < d6[2] < 0.13, d6
+
+
+def test_oracle_loop_equals_the_reference_loop_code(data):
+    """tiny_hybrid.npz = poses of the REFERENCE's OWN RawROAMSystem.run - its Tracker glue, networkx outlier rejection, Keyframe /
+    Map bookkeeping, MotionDistortionSolver on scipy's least_squares, Trajectory - fed by the oracle's warp / LK / detector in place
+    of cv2 / skimage (tests/golden/make_tiny_hybrid.py, build container only).  oracle.OdometryPipeline must give the same poses on
+    all ten pairs, for HEAD's keyframe thresholds and for a keyframe on every frame, without and with the frame-2 swap: the loop
+    restatement (a9, a11-a15) pinned against the reference's code to solver round-off instead of three printed decimals."""
+    traj, pay = data
+    hyb = np.load(os.path.join(HERE, "golden", "tiny_hybrid.npz"))
+    for swap in (False, True):
+        for every in (False, True):
+            want = hyb["poses_%s_%s" % ("swap" if swap else "plain", "every_frame" if every else "head")]
+            frame = [0]
+            kw = dict(keyframe_trans_m=0.0) if every else {}
+            pipe = _swap_pipeline(traj, pay, frame, **kw) if swap else _pipeline(traj, pay)
+            if every and not swap:
+                pipe.kf_trans_sq = 0.0
+            assert np.array_equal(want[0], traj["gt_pose"][0])
+            for t in range(1, 11):
+                frame[0] = t
+                out = pipe.step(np.ascontiguousarray(pay[t]))
+                # (the oracle's lmdif restatement against scipy's MINPACK: <= 4e-6 on the mds goldens; dead-reckoned over ten pairs)
+                assert np.abs(out["pose"][:2] - want[t][:2]).max() <= 2e-5 and abs(out["pose"][2] - want[t][2]) <= 2e-6, (swap, every, t, out["pose"], want[t])
 
 
 def test_frames_6_to_10_stay_in_the_neighbourhood(data):
