@@ -94,6 +94,14 @@ __device__ __forceinline__ uint32_t quant_u8(float v)
     return (uint32_t)(int)__fmul_rn(v, 255.f) & 0xffu;       // (img*255).astype(uint8): truncation
 }
 
+// the same for a bilinear sample of u8 codes: the weights are multiples of 2^-10 that sum to exactly 1 and every sample is at most 1, so
+// every rounded product is at most its weight and every rounded partial sum at most the (representable) sum of the weights: 0 <= v <= 1,
+// v * 255 <= 255 - the truncated value needs no mask
+__device__ __forceinline__ uint32_t quant_u8_unit(float v)
+{
+    return (uint32_t)(int)__fmul_rn(v, 255.f);
+}
+
 template <bool U8>
 __global__ __launch_bounds__(256) void polar_to_cart_kernel(WarpSrc src, int rows, int cols, int R,
                                                             uint8_t *__restrict__ cart_u8, int64_t u8_lane_stride,
@@ -132,11 +140,22 @@ __global__ __launch_bounds__(256) void polar_to_cart_kernel(WarpSrc src, int row
 // the scan: the engine computes it ONCE with the exact arithmetic of warp_pixel and every
 // later warp is a pure gather: 4 B of map per pixel shared by LB lanes of the batch, four
 // u8 taps through L1/L2, 7 float ops, one packed 32-bit store per 4 pixels.
-// u8 -> float32 decode: (float)((double)k * (1.0/255.0)) == (float)k / 255.f for all 256
-// codes (verified exhaustively in tests/test_abi_cpu.py) - 3 cheap ops instead of a divide.
+// u8 -> float32 decode: (float)k / 255.f for all 256 codes (verified exhaustively in tests/test_abi_cpu.py) without a divide and
+// without float64: 1 / 255 split into a float32 head and tail, fma(k, head, k * tail) is the correctly rounded quotient for every
+// code (round 5; rounds 1-4 went through (float)((double)k * (1.0 / 255.0)): a v_cvt_f64_u32 + a half-rate v_mul_f64 + a
+// v_cvt_f32_f64 per sample, and the staging of the polar boxes - one decode per sample and scan - was a third of this kernel's vector
+// instructions).  (float)(byte of a word) is ONE instruction (v_cvt_f32_ubyteN).
+#ifndef WG_DECODE_F64
+#define WG_DECODE_F64 0
+#endif
 __device__ __forceinline__ float code_to_f32(uint32_t k)
 {
+#if WG_DECODE_F64
     return (float)__dmul_rn((double)k, 1.0 / 255.0);
+#else
+    const float kf = (float)k;
+    return __fmaf_rn(kf, 0x1.0101020000000p-8f, __fmul_rn(kf, -0x1.fdfdfe0000000p-33f));            // head + tail = 1 / 255 to 2^-57
+#endif
 }
 
 // pack: ix [0,12) | iy [12,22) | fx [22,27) | fy [27,32)
@@ -206,7 +225,7 @@ template <int M> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
 // written with one 16-byte LDS store (the LDS row pitch bp is a multiple of 4 floats).  wave wvs takes the row
 // groups wvs, wvs+4, ...; the U scans' loads are issued before the first is consumed.
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
-template <int U>
+template <int U, bool CHK>
 __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t lane_stride,
                                          const int32_t *__restrict__ lane_index, int l, int64_t row_stride, int rows,
                                          int cols, int mnx, int mny, int bw, int bp, int bh, int elems, int wvs, int lane,
@@ -231,10 +250,12 @@ __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 float4 v;
-                v.x = (x0 < cols) ? code_to_f32(raw[u] & 255u) : 0.f;
-                v.y = (x0 + 1 < cols) ? code_to_f32((raw[u] >> 8) & 255u) : 0.f;
-                v.z = (x0 + 2 < cols) ? code_to_f32((raw[u] >> 16) & 255u) : 0.f;
-                v.w = (x0 + 3 < cols) ? code_to_f32(raw[u] >> 24) : 0.f;
+                // (CHK: the box reaches past the scan's last range bin - those samples are zero; most boxes do not, and are spared the
+                // four compares and selects per dword)
+                v.x = (!CHK || x0 < cols) ? code_to_f32(raw[u] & 255u) : 0.f;
+                v.y = (!CHK || x0 + 1 < cols) ? code_to_f32((raw[u] >> 8) & 255u) : 0.f;
+                v.z = (!CHK || x0 + 2 < cols) ? code_to_f32((raw[u] >> 16) & 255u) : 0.f;
+                v.w = (!CHK || x0 + 3 < cols) ? code_to_f32(raw[u] >> 24) : 0.f;
                 *reinterpret_cast<float4 *>(drow + u * elems) = v;
             }
         }
@@ -301,7 +322,13 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
     const bool any = mxx >= 0;
     const int bw = mxx - mnx + 2, bh = mxy - mny + 2;
-    const int bp = (bw + 3) & ~3;                     // LDS pitch of a box row: whole 16-byte stores
+#ifndef WG_BP_MODE
+#define WG_BP_MODE 0
+#endif
+    int bp_ = (bw + 3) & ~3;                          // LDS pitch of a box row: whole 16-byte stores
+    if (WG_BP_MODE == 1 && (bp_ & 4) == 0) bp_ += 4;  // (experiment: an odd multiple of four floats - rows k, k + 1, .. start in different banks)
+    if (WG_BP_MODE == 2) { while ((bp_ & 31) != 4) bp_ += 4; }
+    const int bp = bp_;
     const int elems = bp * bh;
     const bool use_box = any && (elems <= WG_BOX_ELEMS);
     int off0[4], off1[4];
@@ -365,6 +392,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
         wb[j] = f32x2{w10[j], w11[j]};
     }
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const bool chk = mnx + bp > cols;                 // some staged column lies past the last range bin (wave-uniform)
     const int per = max(1, min(WG_LB, WG_BOX_ELEMS / elems));
     for (int lb = l0; lb < l1; lb += per) {
         const int nq = min(per, l1 - lb);
@@ -374,10 +402,13 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             const int rem = nq - qb;
             const uint8_t *sp = pool + payload_off;
             float *bq = box + qb * elems;
-            if (rem >= 8 && WG_FILL_U >= 8) { box_fill<8>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 8; }
-            else if (rem >= 4 && WG_FILL_U >= 4) { box_fill<4>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 4; }
-            else if (rem >= 2 && WG_FILL_U >= 2) { box_fill<2>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 2; }
-            else { box_fill<1>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += 1; }
+#define WG_FILL(U_) { if (chk) box_fill<U_, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); \
+                      else box_fill<U_, false>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += U_; }
+            if (rem >= 8 && WG_FILL_U >= 8) WG_FILL(8)
+            else if (rem >= 4 && WG_FILL_U >= 4) WG_FILL(4)
+            else if (rem >= 2 && WG_FILL_U >= 2) WG_FILL(2)
+            else WG_FILL(1)
+#undef WG_FILL
         }
         __syncthreads();
         uint8_t *dq = dst + (int64_t)lb * u8_lane_stride;          // this thread's dword in scan lb, advanced per scan
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             // price of a dozen register moves)
             // (v_cvt_pk_u8_f32 would convert AND place the byte, but it ROUNDS to nearest where the reference's cast truncates - 11.0 ->
             // 10.6 ms with wrong bytes; fed the floor it is exact and SLOWER, 11.5 ms: round 4, measured and dropped)
-            const uint32_t pk = quant_u8(vq[0]) | (quant_u8(vq[1]) << 8) | (quant_u8(vq[2]) << 16) | (quant_u8(vq[3]) << 24);
+            const uint32_t pk = quant_u8_unit(vq[0]) | (quant_u8_unit(vq[1]) << 8) | (quant_u8_unit(vq[2]) << 16) | (quant_u8_unit(vq[3]) << 24);
             const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
             const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
             const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));

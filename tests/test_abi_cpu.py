@@ -124,6 +124,20 @@ def test_u8_decode_identity():
     ref = k.astype(np.float32) / np.float32(255.)
     got = (k.astype(np.float64) * (1.0 / 255.0)).astype(np.float32)
     assert np.array_equal(got, ref)
+    # the warp's float32-only form (round 5, csrc/warp.hip code_to_f32): fma(k, head, k * tail) with head + tail = 1 / 255 - evaluated
+    # here in exact rational arithmetic with one rounding per float32 operation
+    from fractions import Fraction
+
+    def rnd32(fr):
+        f = np.float32(float(fr))
+        cands = [np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))]
+        return min(cands, key=lambda t: (abs(Fraction(float(t)) - fr), int(np.float32(t).view(np.uint32)) & 1))
+
+    head, tail = float.fromhex("0x1.010102p-8"), float.fromhex("-0x1.fdfdfep-33")
+    assert np.float32(head) == head and np.float32(tail) == tail
+    for kk in range(256):
+        low = rnd32(Fraction(kk) * Fraction(tail))
+        assert rnd32(Fraction(kk) * Fraction(head) + Fraction(float(low))) == ref[kk], kk
 
 
 def test_trajectory_and_gt_loader(tmp_path):
