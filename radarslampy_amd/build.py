@@ -25,7 +25,7 @@ def fingerprint(sources):
     while it still matches."""
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(sources)] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    files = [os.path.join(CSRC, f) for f in sorted(sources)] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
     h.update(repr((FLAGS, sorted((k, v) for k, v in EXTRA.items() if k in sources))).encode())
@@ -42,7 +42,7 @@ def _stale(out, deps):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "roam_abi.h")]
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + [os.path.join(HERE, "..", "include", "roam_abi.h")]
     objs, jobs = [], []
     for s in _sources():
         src = os.path.join(CSRC, s)

@@ -64,14 +64,8 @@ __global__ __launch_bounds__(256) void rt_collect_kernel(const roam_lane_result 
 
 // ------------------------------------------------------------------------------------------------ K1 / K2: integral image
 __device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dmul_rn((double)k, 1.0 / 255.0); }
-// the same value - (float)k / 255.f for every code - in float32 only: 1 / 255 as head + tail, fma(k, head, k * tail) (warp.hip code_to_f32,
-// exhaustive check in tests/test_abi_cpu.py); with (float)(byte of a word) = one v_cvt_f32_ubyteN that is three full-rate instructions per
-// tap and no second LDS round trip through a 256-entry table
-__device__ __forceinline__ float rt_decode_f32(float kf) { return __fmaf_rn(kf, 0x1.010102p-8f, __fmul_rn(kf, -0x1.fdfdfep-33f)); }
-#ifndef RI_TAP_DECODE
-#define RI_TAP_DECODE 0                     // 0: four byte reads + four table reads; 1 (round-5 experiment, WRONG and slower - 9.1 against 6.6 ms per 512
-                                            // detections: a 16-bit LDS read at an odd address does not return the two bytes there): two 16-bit reads + arithmetic
-#endif
+// (round 5: the float32-only decode of warp.hip - fma(k, head, k * tail) - in place of the table read was tried in the one-sweep kernel's
+// taps, with byte reads and with 16-bit reads: 9.1 ms per 512 detections against 6.6 with the table; the table stays)
 
 // Two ways to the integral image, chosen on the device by the number of detections of the chunk (only the device knows it):
 //   * rt_integral_kernel (below): one workgroup per detection, the image written once - 12.7 us per detection at 512, but a chain of
@@ -405,13 +399,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                         const float wx1 = __fmul_rn((float)((mk >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
                         const float wy1 = __fmul_rn((float)(mk >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
                         const uint8_t *q = bx + (iy - mny) * bp + (ix - mnx);
-#if RI_TAP_DECODE
-                        const uint32_t u0 = reinterpret_cast<const RtU16 *>(q)->v, u1 = reinterpret_cast<const RtU16 *>(q + bp)->v;
-                        const float s00 = rt_decode_f32((float)(u0 & 255u)), s01 = rt_decode_f32((float)(u0 >> 8));
-                        const float s10 = rt_decode_f32((float)(u1 & 255u)), s11 = rt_decode_f32((float)(u1 >> 8));         // (code 0 = bins past the scan)
-#else
                         const float s00 = lut[q[0]], s01 = lut[q[1]], s10 = lut[q[bp]], s11 = lut[q[bp + 1]];   // lut[0] = 0: bins past the scan
-#endif
                         r_ = __fmul_rn(s00, __fmul_rn(wy0, wx0));
                         r_ = __fadd_rn(r_, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
                         r_ = __fadd_rn(r_, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
