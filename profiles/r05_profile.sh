@@ -30,3 +30,6 @@ timeout 900 bash profiles/pmc_fused.sh > $O/pmc_fused_kernels.txt 2>&1
 LANES=512 timeout 600 bash profiles/pmc_warp.sh > $O/pmc_warp.txt 2>&1
 for f in $O/bench_default_20_5.json $O/bench_default_50_3.json $O/bench_config5_world1.json $O/bench_h2d_streaming.json; do cut -c1-220 $f; done
 cat $O/time_clique.txt $O/time_kernels.txt; head -12 $O/kernel_stats.csv | cut -d, -f1-5
+# only the summaries travel back (gpurun merges at most 64 MiB): the raw counter / trace CSVs stay on the box
+rm -rf gpurun_out/pmc_det gpurun_out/pmc_fused gpurun_out/pmcw $O/prof gpurun_out/pmc_rt 2>/dev/null
+du -sh gpurun_out | tail -1

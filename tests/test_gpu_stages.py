@@ -225,6 +225,27 @@ def test_reject_outliers_tie_break_is_networkx_order(ctx):
     assert differ >= 15, differ
 
 
+def test_reject_outliers_tie_break_on_large_tie_heavy_graphs(ctx):
+    """the same construction at 600 to 1024 correspondences (round-4 advisor: the device walk had only been compared with the oracle
+    up to K = 520; larger sets were checked on unique cliques only): sets above 512 keys use the 2048-slot table path of nx_walk"""
+    rng = np.random.default_rng(2025)
+    differ = ties = 0
+    for K in (600, 700, 801, 903, 960):                       # (the oracle's walk takes a minute at 1024: unique cliques cover that size)
+        p = rng.uniform(60, 1960, size=(K, 2)).astype(np.float32)
+        th = rng.uniform(-0.02, 0.02)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        n = ((p - 1012) @ R.T + 1012 + rng.uniform(-20, 20, 2)).astype(np.float32)
+        n += rng.normal(0, 1.2, size=(K, 2)).astype(np.float32)
+        movers = rng.permutation(K)[:int(K * 0.25)]
+        n[movers] += rng.normal(0, 12, size=(len(movers), 2)).astype(np.float32)
+        mask, n_in, flags, adj = ctx.reject_outliers(p, n, oracle.DIST_THRESHOLD_PX, want_adj=True)
+        size, omask, st = oracle.max_clique_nx(adj)
+        assert flags & 1, K
+        assert n_in == size and np.array_equal(mask, omask), K
+        differ += not np.array_equal(omask, oracle.max_clique_lex(adj)[1])
+    assert differ >= 2, differ
+
+
 # ------------------------------------------------------------------ a10 Kabsch
 def test_kabsch(ctx, golden):
     g = golden("kabsch")
