@@ -211,8 +211,16 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
             }
             c.nodes++;
             if (c.node_limit > 0 && c.nodes > c.node_limit) { c.complete = false; return best; }
-            // matching bound on the conflict graph of P
-            {
+            // matching bound on the conflict graph of P - from node CQ_MATCH_AFTER on.  The greedy matching is a sequential pass over the
+            // vertices of P (~0.25 us each on a lone wave); on scan-pair graphs - real and synthetic, 53 to 256 correspondences - it never
+            // pruned a node (same node counts with and without) and was 80 % of the solver's time (round 5: profiles/clique_lone.py,
+            // 4.8 -> 1.1 ms over sixteen real / bench-like pairs for phase 1; u256 11.9 -> 4.5 ms per 4096 problems).  It is kept for
+            // searches that grow past a few hundred nodes, where it did earn its cost in round 2
+#ifndef CQ_MATCH_AFTER
+#define CQ_MATCH_AFTER 256
+#endif
+#ifndef CQ_EXP_NOMATCH
+            if (c.nodes > CQ_MATCH_AFTER) {
                 const int cnt = bs_count(P);
                 uint64_t Q = P;
                 int slack = size + cnt - best;                          // prune once the matching reaches `slack`
@@ -230,6 +238,7 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
                 }
                 if (pruned) continue;
             }
+#endif
             depth++;
             if (lane < nw) {
                 c.stk[((int64_t)depth * 2) * c.nws + lane] = P;
