@@ -48,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--stream", action="store_true", help="single-sequence mode: one lane, pinned ring, result ring (configs 3 / 4)")
     ap.add_argument("--stream-frames", type=int, default=240, help="frames of the --stream sequence")
     ap.add_argument("--png", action="store_true", help="with --stream: also feed the sequence from PNG files (written first, untimed) - decode pool + H2D + step timed")
-    ap.add_argument("--png-workers", type=int, default=0, help="host threads inflating PNGs ahead of the engine (0 = min(16, cores / 2))")
+    ap.add_argument("--png-workers", type=int, default=0, help="host threads inflating PNGs ahead of the engine (0 = min(32, cores / 2))")
     ap.add_argument("--stream-start", type=int, default=280, help="first ground-truth motion of full_seq_1 used by --stream (the vehicle stands still for the first ~230 frames)")
     ap.add_argument("--cpu-pairs", type=int, default=120, help="scan pairs timed on the CPU oracle, 1 core (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the N-core CPU leg (-1 = half the logical cores, 0 = skip)")
@@ -834,7 +834,7 @@ def stream_png_measure(recs, poses, md, ctx, workers):
     import tempfile
     from PIL import Image
     from radarslampy_amd.RawROAMSystem import stream_records
-    from radarslampy_amd.parseData import prefetchRadarRecords, readRadarRecord
+    from radarslampy_amd.parseData import RecordDecodePool, prefetchRadarRecords, readRadarRecord
     n = len(recs)
     flags = {"rejectOutliers": True, "correctMotionDistortion": md}
     d = tempfile.mkdtemp(prefix="roam_png_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -850,21 +850,34 @@ def stream_png_measure(recs, poses, md, ctx, workers):
         one = (time.perf_counter() - t0) / 24
         t0 = time.perf_counter()
         k = sum(1 for _ in prefetchRadarRecords(paths, workers))
-        dec = time.perf_counter() - t0
+        dec_thr = time.perf_counter() - t0
         assert k == n
-        stream_records(prefetchRadarRecords(paths[:12], workers), 12, poses[0], flags, ctx)          # warm-up
+        with RecordDecodePool(workers) as pool:                                                       # (start-up of the processes: untimed)
+            for _ in pool.records(paths[:64]):                                                        # ... every worker has finished importing
+                pass
+            t0 = time.perf_counter()
+            k = sum(1 for _ in pool.records(paths))
+            dec = time.perf_counter() - t0
+            assert k == n
+            stream_records(pool.records(paths[:12]), 12, poses[0], flags, ctx)                       # warm-up
+            t0 = time.perf_counter()
+            est, _ = stream_records(pool.records(paths), n, poses[0], flags, ctx)
+            dt = time.perf_counter() - t0
         t0 = time.perf_counter()
-        est, _ = stream_records(prefetchRadarRecords(paths, workers), n, poses[0], flags, ctx)
-        dt = time.perf_counter() - t0
+        est_t, _ = stream_records(prefetchRadarRecords(paths, workers), n, poses[0], flags, ctx)     # the thread pool of the same size
+        dtt = time.perf_counter() - t0
+        assert est_t.tobytes() == est.tobytes()
         t0 = time.perf_counter()
         est1, _ = stream_records(prefetchRadarRecords(paths, 1), n, poses[0], flags, ctx)            # the decode on the feeding thread (round 4)
         dt1 = time.perf_counter() - t0
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    w = workers if workers > 0 else max(1, min(16, (os.cpu_count() or 2) // 2))
-    return est, est1, {"png_inclusive_pairs_per_s": round((n - 1) / dt, 2), "png_inclusive_pairs_per_s_one_decode_thread": round((n - 1) / dt1, 2),
-                       "png_decode_only_frames_per_s": round(n / dec, 1), "png_decode_ms_per_frame_one_thread": round(one * 1e3, 2),
-                       "png_decode_threads": w, "png_mean_file_bytes": int(size)}
+    w = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 2))
+    return est, est1, {"png_inclusive_pairs_per_s": round((n - 1) / dt, 2), "png_inclusive_pairs_per_s_thread_pool": round((n - 1) / dtt, 2),
+                       "png_inclusive_pairs_per_s_one_decode_thread": round((n - 1) / dt1, 2),
+                       "png_decode_only_frames_per_s": round(n / dec, 1), "png_decode_only_frames_per_s_thread_pool": round(n / dec_thr, 1),
+                       "png_decode_ms_per_frame_one_thread": round(one * 1e3, 2),
+                       "png_decode_processes": w, "png_mean_file_bytes": int(size)}
 
 
 def run_stream(args):

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parseData import getRadarImgPaths, prefetchRadarRecords
+from .parseData import RecordDecodePool, getRadarImgPaths, prefetchRadarRecords
 from .trajectoryPlotting import Trajectory, computePosesRMSE, getGroundTruthTrajectory
 from .utils import radarImgPathToTimestamp
 
@@ -25,7 +25,7 @@ LAG = 2             # results are read this many steps behind the enqueue front
 class RawROAMSystem:
     def __init__(self, sequenceName: str, paramFlags: dict = None, hasGroundTruth: bool = True, dataRoot: str = "data",
                  ctx: _ffi.Context = None, decodeWorkers: int = 0) -> None:
-        self.decodeWorkers = decodeWorkers              # host threads inflating PNGs ahead of the engine (0: min(16, cores / 2))
+        self.decodeWorkers = decodeWorkers              # host processes inflating PNGs ahead of the engine (0: min(32, cores / 2))
         self.sequenceName, self.paramFlags, self.hasGroundTruth, self.dataRoot = sequenceName, dict(paramFlags or {}), hasGroundTruth, dataRoot
         seq = os.path.join(dataRoot, sequenceName)
         self.filePaths = {"data": os.path.join(seq, "radar"), "timestamp": os.path.join(seq, "radar.timestamps")}
@@ -53,10 +53,14 @@ class RawROAMSystem:
             if initPose is None:
                 initPose = self.gtTraj.getPoseAtTimes(stamps[0])
         initPose = np.zeros(3) if initPose is None else np.asarray(initPose, np.float64)
-        # PNG inflate runs ahead of the loop on a pool of host threads (parseData.prefetchRadarRecords): the thread that feeds the pinned
-        # ring only copies decoded records
-        records = prefetchRadarRecords([self.imgPathArr[i] for i in frames], self.decodeWorkers)
-        poses, log = stream_records(records, len(frames), initPose, self.paramFlags, self.ctx)
+        # PNG inflate runs ahead of the loop on a pool of host processes (parseData.RecordDecodePool; a handful of frames: threads): the
+        # thread that feeds the pinned ring only copies decoded records
+        paths = [self.imgPathArr[i] for i in frames]
+        if len(paths) >= 64 and self.decodeWorkers != 1:
+            with RecordDecodePool(self.decodeWorkers) as pool:
+                poses, log = stream_records(pool.records(paths), len(frames), initPose, self.paramFlags, self.ctx)
+        else:
+            poses, log = stream_records(prefetchRadarRecords(paths, self.decodeWorkers), len(frames), initPose, self.paramFlags, self.ctx)
         self.estTraj = Trajectory([stamps[0]], [initPose])
         self.estTraj.extend_absolute(stamps[1:], poses)
         for k, e in enumerate(log):

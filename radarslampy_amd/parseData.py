@@ -59,12 +59,12 @@ def prefetchRadarRecords(imgPaths, workers: int = 0, depth: int = 0):
     frame k with cv2.imread inside its loop, parseData.py:160-226 / RawROAMSystem.py:162-165; a 1.5 MB Oxford PNG inflates in
     10-20 ms, one thread feeds 50-100 frames/s, the engine takes 700-1100 pairs/s of one sequence).  zlib inflate and Pillow's
     decoder release the GIL, so threads scale; at most `depth` decoded frames (1.5 MB each) wait for the consumer.
-    workers = 0: min(16, cores / 2); depth = 0: 3 x workers.  A frame that fails to decode raises when ITS turn comes."""
+    workers = 0: min(32, cores / 2); depth = 0: 3 x workers.  A frame that fails to decode raises when ITS turn comes."""
     import os
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     paths = list(imgPaths)
-    workers = workers if workers > 0 else max(1, min(16, (os.cpu_count() or 2) // 2))
+    workers = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 2))
     depth = depth if depth > 0 else 3 * workers
     if workers == 1:
         for p in paths:
@@ -80,6 +80,105 @@ def prefetchRadarRecords(imgPaths, workers: int = 0, depth: int = 0):
             yield pending.popleft().result()
     finally:
         pool.shutdown(wait=True, cancel_futures=True)
+
+
+def _decode_worker(shm_name, rec_bytes, tasks, done):
+    """body of one process of RecordDecodePool: decode the PNGs it is handed into their slots of the shared ring"""
+    from multiprocessing import shared_memory
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        buf = np.ndarray((shm.size,), np.uint8, buffer=shm.buf)
+        while True:
+            job = tasks.get()
+            if job is None:
+                break
+            idx, path, slot = job
+            try:
+                rec = readRadarRecord(path)
+                if rec.size > rec_bytes:
+                    raise ValueError(f"{path}: {rec.shape} does not fit a {rec_bytes}-byte slot")
+                buf[slot * rec_bytes:slot * rec_bytes + rec.size] = rec.ravel()
+                done.put((idx, slot, rec.shape, None, None))
+            except BaseException as ex:                          # noqa: BLE001 - reported at the frame's turn
+                done.put((idx, slot, None, type(ex).__name__, str(ex)))
+        del buf
+    finally:
+        shm.close()
+
+
+class RecordDecodePool:
+    """PNG inflate on a pool of host PROCESSES (8f-f2).  Threads stop scaling at ~1 300 frames/s on a 256-core host - what Pillow does
+    around its decoder holds the GIL for ~0.8 ms per frame, and the thread that feeds the pinned ring queues for it too - which is enough
+    for the single-sequence driver with motion distortion (700 pairs/s) and not without (1 200).  Processes decode into the slots of a
+    ring in shared memory; the consumer gets the frames IN ORDER as views of those slots (valid until it asks for the next one).
+    workers = 0: min(32, cores / 2); depth (slots, 1.5 MB each) = 0: 2 x workers.  Use as a context manager, or close()."""
+
+    def __init__(self, workers: int = 0, depth: int = 0, rec_bytes: int = 400 * 3779):
+        import multiprocessing as mp
+        import os
+        from multiprocessing import shared_memory
+        self.workers = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 2))
+        self.depth = depth if depth > 0 else 2 * self.workers
+        self.rec_bytes = int(rec_bytes)
+        self._shm = shared_memory.SharedMemory(create=True, size=self.depth * self.rec_bytes)
+        self._buf = np.ndarray((self._shm.size,), np.uint8, buffer=self._shm.buf)
+        ctx = mp.get_context("spawn")                          # fresh interpreters: nothing of the parent's GPU state is inherited
+        self._tasks, self._done = ctx.Queue(), ctx.Queue()
+        self._outstanding = 0
+        self._procs = [ctx.Process(target=_decode_worker, args=(self._shm.name, self.rec_bytes, self._tasks, self._done), daemon=True)
+                       for _ in range(self.workers)]
+        for p in self._procs:
+            p.start()
+
+    def records(self, imgPaths):
+        paths = list(imgPaths)
+        self._drain()                                           # (an earlier iteration that was abandoned half way)
+        free = list(range(self.depth))
+        ready, nxt, want = {}, 0, 0
+        try:
+            while want < len(paths):
+                while nxt < len(paths) and free:
+                    self._tasks.put((nxt, paths[nxt], free.pop()))
+                    self._outstanding += 1
+                    nxt += 1
+                while want not in ready:
+                    idx, slot, shape, exn, msg = self._done.get()
+                    self._outstanding -= 1
+                    ready[idx] = (slot, shape, exn, msg)
+                slot, shape, exn, msg = ready.pop(want)
+                want += 1
+                if exn is not None:
+                    raise (FileNotFoundError(msg) if exn == "FileNotFoundError" else RuntimeError(f"{exn}: {msg}"))
+                n = int(np.prod(shape))
+                yield self._buf[slot * self.rec_bytes:slot * self.rec_bytes + n].reshape(shape)
+                free.append(slot)                               # the consumer is back: it has copied the frame
+        finally:
+            self._drain()                                       # nothing of this iteration is left in flight when it ends, however it ends
+
+    def _drain(self):
+        while self._outstanding > 0:
+            self._done.get()
+            self._outstanding -= 1
+
+    def close(self):
+        if self._shm is None:
+            return
+        for _ in self._procs:
+            self._tasks.put(None)
+        for p in self._procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()                                        # (its own child, by handle)
+        self._buf = None
+        self._shm.close()
+        self._shm.unlink()
+        self._shm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def getPolarImageFromImgPaths(imgPathArr, index: int) -> np.ndarray:

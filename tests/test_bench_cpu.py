@@ -173,3 +173,31 @@ def test_png_prefetch_pool_keeps_the_order_and_reports_a_bad_frame_at_its_turn(t
         assert np.array_equal(next(it), want[i])
     with pytest.raises(FileNotFoundError):
         next(it)
+
+
+def test_png_decode_process_pool_keeps_the_order(tmp_path):
+    """parseData.RecordDecodePool: the same contract as the thread pool on a pool of processes with a shared-memory ring - frames
+    in path order (views valid until the next one is asked for), a missing file raises at its turn, the pool can be reused"""
+    import numpy as np
+    import pytest
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from radarslampy_amd.parseData import RecordDecodePool
+    rng = np.random.default_rng(6)
+    paths, want = [], []
+    for i in range(19):
+        r = rng.integers(0, 256, (40, 379), dtype=np.uint8)
+        p = tmp_path / f"{i:04d}.png"
+        Image.fromarray(r).save(p)
+        paths.append(str(p)); want.append(r)
+    with RecordDecodePool(workers=3, depth=4, rec_bytes=40 * 379) as pool:
+        for _ in range(2):
+            got = [g.copy() for g in pool.records(paths)]
+            assert len(got) == 19 and all(np.array_equal(g, w) for g, w in zip(got, want))
+        it = pool.records(paths[:3] + [str(tmp_path / "missing.png")] + paths[3:6])
+        for i in range(3):
+            assert np.array_equal(next(it), want[i])
+        with pytest.raises(FileNotFoundError):
+            next(it)
+        got = [g.copy() for g in pool.records(paths[5:9])]                 # still usable afterwards
+        assert all(np.array_equal(g, w) for g, w in zip(got, want[5:9]))
