@@ -246,6 +246,20 @@ def test_reject_outliers_tie_break_on_large_tie_heavy_graphs(ctx):
     assert differ >= 2, differ
 
 
+def test_reject_outliers_on_the_correspondence_sets_of_real_pairs(ctx, golden):
+    """the sixteen correspondence sets the loop produces on the reference's ten real data/tiny pairs and on six bench-like pairs
+    (tests/golden/clique_lone_sets.npz, made by profiles/clique_lone.py from the oracle's loop): 53-178 correspondences, 2- to 14-way
+    ties between maximum cliques - the device's mask is the oracle's networkx-order clique on every one, proven"""
+    g = golden("clique_lone_sets")
+    tags = sorted(k[:-5] for k in g.files if k.endswith("_prev"))
+    assert len(tags) == 16
+    for tag in tags:
+        p, n = g[tag + "_prev"], g[tag + "_new"]
+        mask, n_in, flags, adj = ctx.reject_outliers(p, n, oracle.DIST_THRESHOLD_PX, want_adj=True)
+        size, omask, _ = oracle.max_clique_nx(adj)
+        assert flags & 1 and n_in == size and np.array_equal(mask, omask), tag
+
+
 # ------------------------------------------------------------------ a10 Kabsch
 def test_kabsch(ctx, golden):
     g = golden("kabsch")
