@@ -69,6 +69,19 @@ BP_HDN void bp_adjust_heap(IDX *f, int hole, int len, IDX value, const int16_t *
     f[hole] = value;
 }
 
+// introselect's fallback once its depth budget is spent: __heap_select(first, nth + 1, last) + swap
+template <typename IDX>
+BP_HDN void bp_heap_select_nth(IDX *idx, int first, int nth, int last, const int16_t *xy, int d)
+{
+    IDX *f = idx + first;
+    const int len = nth + 1 - first;
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; parent--) { bp_adjust_heap(f, parent, len, f[parent], xy, d); if (parent == 0) break; }
+    for (int i = nth + 1; i < last; i++)
+        if (BP_KEY(idx[i]) < BP_KEY(f[0])) { IDX v = idx[i]; idx[i] = f[0]; bp_adjust_heap(f, 0, len, v, xy, d); }
+    IDX t = idx[first]; idx[first] = idx[nth]; idx[nth] = t;
+}
+
 template <typename IDX>
 BP_HDN void bp_nth_element(IDX *idx, int first, int nth, int last, const int16_t *xy, int d)
 {
@@ -77,16 +90,7 @@ BP_HDN void bp_nth_element(IDX *idx, int first, int nth, int last, const int16_t
     for (int n = last - first; n > 1; n >>= 1) depth++;
     depth *= 2;
     while (last - first > 3) {
-        if (depth == 0) {                                   // __heap_select(first, nth + 1, last) + swap
-            IDX *f = idx + first;
-            const int len = nth + 1 - first;
-            if (len >= 2)
-                for (int parent = (len - 2) / 2;; parent--) { bp_adjust_heap(f, parent, len, f[parent], xy, d); if (parent == 0) break; }
-            for (int i = nth + 1; i < last; i++)
-                if (BP_KEY(idx[i]) < BP_KEY(f[0])) { IDX v = idx[i]; idx[i] = f[0]; bp_adjust_heap(f, 0, len, v, xy, d); }
-            IDX t = idx[first]; idx[first] = idx[nth]; idx[nth] = t;
-            return;
-        }
+        if (depth == 0) { bp_heap_select_nth(idx, first, nth, last, xy, d); return; }
         depth--;
         const int mid = first + (last - first) / 2;
         const int a = first + 1, b = mid, c = last - 1;

@@ -987,6 +987,153 @@ template <bool SMALL> struct RtBlobLds {
     int vals[8];
 };
 
+// ---- the large nodes of the k-d tree, built by the WHOLE wavefront (round 5).  bp_build_node - bounds, libstdc++'s introselect, scipy's
+// partition pass - on one lane is a chain of dependent LDS reads: ~110 us for the 530-element root of a real frame, 55 for its children
+// (profiles: ranking + tree build were 323 of the 640 us of a lone detection's bookkeeping).  Both partitions are two-pointer scans that swap
+// the i-th misplaced element from the left with the i-th from the right until the pointers cross; elements between the pointers are never
+// touched before the pointers get there, so the two ordered lists of misplaced POSITIONS can be taken from the array as it stands (ballot +
+// prefix count per 64 positions), the number of swaps is the number of i with L[i] < R[i], and the swaps are independent of each other:
+// the same array, element for element, as the sequential code (an element equal to the pivot sits in both lists; it stops the scan from
+// whichever side reaches it first, exactly as there).  Median-of-three, the <= 3-element insertion sort and the rare heap-select
+// fallback stay sequential (uniform values / lane 0).  Lp, Rp: scratch of (end - start) uint16 each.
+#define RB_WAVE_MIN 100                     // nodes with more elements take this path (a level of eight 66-element nodes is faster lane by lane)
+__device__ __forceinline__ int rb_key(const BpPt *pt, int i, int d) { return (int16_t)(pt[i].v >> (16 * d)); }
+
+// unguarded Hoare partition of [first + 1, last) around piv = key(first) as std::__unguarded_partition leaves it; returns the cut
+__device__ int rb_partition_hoare(BpPt *pt, int first, int last, int d, int lane, uint16_t *Lp, uint16_t *Rp)
+{
+    const int piv = rb_key(pt, first, d);
+    const uint64_t below = (1ull << lane) - 1ull;
+    int nL = 0, nR = 0;
+    // one pass over [first, last): L = positions >= first + 1 with key >= piv, ascending; R = positions with key <= piv, stored ascending
+    // too and read from its end (R[i] = Rp[nR - 1 - i])
+    for (int c0 = first; c0 < last; c0 += 64) {
+        const int pos = c0 + lane;
+        const int k = pos < last ? rb_key(pt, pos, d) : 0;
+        const bool ge = pos < last && pos > first && k >= piv, le = pos < last && k <= piv;
+        const uint64_t bl = __ballot(ge), br = __ballot(le);
+        if (ge) Lp[nL + __popcll(bl & below)] = (uint16_t)pos;
+        if (le) Rp[nR + __popcll(br & below)] = (uint16_t)pos;
+        nL += __popcll(bl); nR += __popcll(br);
+    }
+    __syncthreads();
+    const int nm = min(nL, nR);
+    int kk = 0;
+    for (int i0 = 0; i0 < nm; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t bal = __ballot(i < nm && Lp[i] < Rp[nR - 1 - i]);
+        kk += __popcll(bal);
+        if (__popcll(bal) < min(64, nm - i0)) break;                       // (L ascends, R descends: once crossed, crossed for good)
+    }
+    for (int i = lane; i < kk; i += 64) { const int x = Lp[i], y = Rp[nR - 1 - i]; const BpPt t = pt[x]; pt[x] = pt[y]; pt[y] = t; }
+    const int cut = kk < nL ? (int)Lp[kk] : last;
+    __syncthreads();
+    return cut;
+}
+
+// std::nth_element(first, nth, last) on pt by coordinate d, element for element
+__device__ void rb_nth_element_wave(BpPt *pt, int first, int nth, int last, int d, int lane, uint16_t *Lp, uint16_t *Rp)
+{
+    if (first == last || nth == last) return;
+    int depth = 0;
+    for (int n = last - first; n > 1; n >>= 1) depth++;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) {                                                   // introselect's fallback: sequential, as bp_nth_element has it
+            if (lane == 0) bp_heap_select_nth(pt, first, nth, last, (const int16_t *)nullptr, d);
+            __syncthreads();
+            return;
+        }
+        depth--;
+        const int mid = first + (last - first) / 2, ia = first + 1, ib = mid, ic = last - 1;
+        const int ka = rb_key(pt, ia, d), kb = rb_key(pt, ib, d), kc = rb_key(pt, ic, d);
+        int sm;                                                             // __move_median_to_first
+        if (ka < kb) sm = kb < kc ? ib : (ka < kc ? ic : ia);
+        else sm = ka < kc ? ia : (kb < kc ? ic : ib);
+        __syncthreads();
+        if (lane == 0) { const BpPt t = pt[first]; pt[first] = pt[sm]; pt[sm] = t; }
+        __syncthreads();
+        const int cut = rb_partition_hoare(pt, first, last, d, lane, Lp, Rp);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    if (lane == 0)
+        for (int i = first + 1; i < last; i++) {                            // __insertion_sort
+            const BpPt v = pt[i];
+            const int kv = (int16_t)(v.v >> (16 * d));
+            if (kv < rb_key(pt, first, d)) { for (int j = i; j > first; j--) pt[j] = pt[j - 1]; pt[first] = v; }
+            else { int j = i; while (kv < rb_key(pt, j - 1, d)) { pt[j] = pt[j - 1]; j--; } pt[j] = v; }
+        }
+    __syncthreads();
+}
+
+// bp_build_node by the whole wavefront (uniform start / end); the same return value and node fields
+__device__ int rb_build_node_wave(BpPt *pt, int start, int end, BpNode &nd, int lane, uint16_t *Lp, uint16_t *Rp)
+{
+    nd.start = (int16_t)start; nd.end = (int16_t)end; nd.less = nd.greater = -1; nd.split_dim = -1; nd.split = 0;
+    if (end - start <= BP_LEAF) return -1;
+    int mx0 = -32768, mn0 = 32767, mx1 = -32768, mn1 = 32767;
+    for (int j = start + lane; j < end; j += 64) {
+        const int v0 = rb_key(pt, j, 0), v1 = rb_key(pt, j, 1);
+        mx0 = max(mx0, v0); mn0 = min(mn0, v0); mx1 = max(mx1, v1); mn1 = min(mn1, v1);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        mx0 = max(mx0, __shfl_xor(mx0, m)); mn0 = min(mn0, __shfl_xor(mn0, m));
+        mx1 = max(mx1, __shfl_xor(mx1, m)); mn1 = min(mn1, __shfl_xor(mn1, m));
+    }
+    int d = 0, size = 0;
+    if (mx0 - mn0 > size) { d = 0; size = mx0 - mn0; }
+    if (mx1 - mn1 > size) { d = 1; size = mx1 - mn1; }
+    if (size <= 0) return -1;
+    const int half = (end - start) / 2;
+    rb_nth_element_wave(pt, start, start + half, end, d, lane, Lp, Rp);
+    int split = rb_key(pt, start + half, d);
+    // scipy's partition pass: p advances over keys < split, q retreats over keys >= split, misplaced pairs are swapped: afterwards the
+    // keys below the split fill [start, p)
+    const uint64_t below = (1ull << lane) - 1ull;
+    int nL = 0, nR = 0;
+    for (int c0 = start; c0 < end; c0 += 64) {
+        const int pos = c0 + lane;
+        const int k = pos < end ? rb_key(pt, pos, d) : 0;
+        const bool ge = pos < end && k >= split, lt = pos < end && k < split;
+        const uint64_t bl = __ballot(ge), br = __ballot(lt);
+        if (ge) Lp[nL + __popcll(bl & below)] = (uint16_t)pos;
+        if (lt) Rp[nR + __popcll(br & below)] = (uint16_t)pos;
+        nL += __popcll(bl); nR += __popcll(br);
+    }
+    __syncthreads();
+    {
+        const int nm = min(nL, nR);
+        int kk = 0;
+        for (int i0 = 0; i0 < nm; i0 += 64) {
+            const int i = i0 + lane;
+            const uint64_t bal = __ballot(i < nm && Lp[i] < Rp[nR - 1 - i]);
+            kk += __popcll(bal);
+            if (__popcll(bal) < min(64, nm - i0)) break;
+        }
+        for (int i = lane; i < kk; i += 64) { const int x = Lp[i], y = Rp[nR - 1 - i]; const BpPt t = pt[x]; pt[x] = pt[y]; pt[y] = t; }
+    }
+    __syncthreads();
+    int p = start + nR;                                                     // = start + the number of keys below the split
+    if (p == start || p == end) {                                           // (no point on one side: slide to the smallest / largest - sequential, rare)
+        if (lane == 0) {
+            if (p == start) {
+                int j = start; split = rb_key(pt, j, d);
+                for (int k = start + 1; k < end; k++) if (rb_key(pt, k, d) < split) { j = k; split = rb_key(pt, j, d); }
+                const BpPt t = pt[start]; pt[start] = pt[j]; pt[j] = t;
+            } else {
+                int j = end - 1; split = rb_key(pt, j, d);
+                for (int k = start; k < end - 1; k++) if (rb_key(pt, k, d) > split) { j = k; split = rb_key(pt, j, d); }
+                const BpPt t = pt[end - 1]; pt[end - 1] = pt[j]; pt[j] = t;
+            }
+        }
+        __syncthreads();
+        split = rb_key(pt, p == start ? start : end - 1, d);
+        p = p == start ? start + 1 : end - 1;
+    }
+    nd.split_dim = (int16_t)d; nd.split = split;
+    return p;
+}
+
 template <bool SMALL>
 __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
 {
@@ -1050,7 +1197,19 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
                 const bool act = me < hi;
                 BpNode nd;
                 int p = -1, start = 0, end = 0;
-                if (act) { start = L.nodes[me].start; end = L.nodes[me].end; p = bp_build_node(L.xy, pt, start, end, nd); }
+                if (act) { start = L.nodes[me].start; end = L.nodes[me].end; }
+                // the large nodes of the chunk one at a time by the whole wave, the others lane by lane
+                uint64_t big = __ballot(act && end - start > RB_WAVE_MIN);
+                const uint64_t bigs = big;
+                while (big) {
+                    const int j = __ffsll((long long)big) - 1;
+                    big &= big - 1;
+                    BpNode ndw;
+                    const int pw = rb_build_node_wave(pt, __builtin_amdgcn_readlane(start, j), __builtin_amdgcn_readlane(end, j), ndw, lane,
+                                                      reinterpret_cast<uint16_t *>(L.pl), reinterpret_cast<uint16_t *>(L.pl) + CP::NP);
+                    if (lane == j) { p = pw; nd = ndw; }
+                }
+                if (act && !((bigs >> lane) & 1ull)) p = bp_build_node(L.xy, pt, start, end, nd);
                 const uint64_t bal = __ballot(act && p >= 0);
                 const int kids = 2 * __popcll(bal);
                 if (nn + kids > CP::NNODE) { nn = -1; break; }                 // (uniform)
