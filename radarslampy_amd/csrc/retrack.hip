@@ -994,7 +994,7 @@ template <bool SMALL> struct RtBlobLds {
 // touched before the pointers get there, so the two ordered lists of misplaced POSITIONS can be taken from the array as it stands (ballot +
 // prefix count per 64 positions), the number of swaps is the number of i with L[i] < R[i], and the swaps are independent of each other:
 // the same array, element for element, as the sequential code (an element equal to the pivot sits in both lists; it stops the scan from
-// whichever side reaches it first, exactly as there).  Median-of-three, the <= 3-element insertion sort and the rare heap-select
+// whichever side reaches it first, exactly as there; checked against the sequential algorithms on 20 000 random arrays with heavy ties).  Median-of-three, the <= 3-element insertion sort and the rare heap-select
 // fallback stay sequential (uniform values / lane 0).  Lp, Rp: scratch of (end - start) uint16 each.
 #define RB_WAVE_MIN 100                     // nodes with more elements take this path (a level of eight 66-element nodes is faster lane by lane)
 __device__ __forceinline__ int rb_key(const BpPt *pt, int i, int d) { return (int16_t)(pt[i].v >> (16 * d)); }
@@ -1026,7 +1026,9 @@ __device__ int rb_partition_hoare(BpPt *pt, int first, int last, int d, int lane
         if (__popcll(bal) < min(64, nm - i0)) break;                       // (L ascends, R descends: once crossed, crossed for good)
     }
     for (int i = lane; i < kk; i += 64) { const int x = Lp[i], y = Rp[nR - 1 - i]; const BpPt t = pt[x]; pt[x] = pt[y]; pt[y] = t; }
-    const int cut = kk < nL ? (int)Lp[kk] : last;
+    // where the left pointer stops: the next position with a key >= piv in the array AS IT IS NOW - the next entry of L, or the smallest
+    // position the swaps have just filled with such a key (R[kk - 1]) when the pointer runs into the swapped region first
+    const int cut = min(kk < nL ? (int)Lp[kk] : last, kk > 0 ? (int)Rp[nR - kk] : last);
     __syncthreads();
     return cut;
 }
