@@ -142,7 +142,7 @@ class RecordDecodePool:
                     self._outstanding += 1
                     nxt += 1
                 while want not in ready:
-                    idx, slot, shape, exn, msg = self._done.get()
+                    idx, slot, shape, exn, msg = self._get_done()
                     self._outstanding -= 1
                     ready[idx] = (slot, shape, exn, msg)
                 slot, shape, exn, msg = ready.pop(want)
@@ -155,9 +155,20 @@ class RecordDecodePool:
         finally:
             self._drain()                                       # nothing of this iteration is left in flight when it ends, however it ends
 
+    def _get_done(self):
+        import queue
+        while True:
+            try:
+                return self._done.get(timeout=1.0)
+            except queue.Empty:
+                dead = [p.exitcode for p in self._procs if not p.is_alive()]
+                if dead:                                        # (e.g. spawned from a __main__ that is not an importable file)
+                    self._outstanding = 0
+                    raise RuntimeError(f"RecordDecodePool: {len(dead)} of {self.workers} decode processes died (exit codes {dead[:4]})")
+
     def _drain(self):
         while self._outstanding > 0:
-            self._done.get()
+            self._get_done()
             self._outstanding -= 1
 
     def close(self):

@@ -201,3 +201,23 @@ def test_png_decode_process_pool_keeps_the_order(tmp_path):
             next(it)
         got = [g.copy() for g in pool.records(paths[5:9])]                 # still usable afterwards
         assert all(np.array_equal(g, w) for g, w in zip(got, want[5:9]))
+
+
+def test_png_decode_process_pool_reports_dead_workers(tmp_path):
+    """a pool whose decode processes cannot start (spawned from a __main__ that is no importable file: `python -` from stdin) raises
+    instead of waiting for frames for ever"""
+    from PIL import Image
+    import numpy as np
+    p = tmp_path / "a.png"
+    Image.fromarray(np.zeros((4, 16), np.uint8)).save(p)
+    code = (f"import sys; sys.path.insert(0, {ROOT!r})\n"
+            "from radarslampy_amd.parseData import RecordDecodePool\n"
+            "pool = RecordDecodePool(workers=2, depth=2, rec_bytes=64)\n"
+            "try:\n"
+            f"    list(pool.records([{str(p)!r}]))\n"
+            "except RuntimeError as e:\n"
+            "    print('RAISED', e)\n"
+            "finally:\n"
+            "    pool.close()\n")
+    out = subprocess.run([sys.executable, "-"], input=code, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert "RAISED RecordDecodePool: 2 of 2 decode processes died" in out.stdout, out.stdout + out.stderr[-2000:]
