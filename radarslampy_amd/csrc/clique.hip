@@ -62,6 +62,10 @@ hipError_t launch_consistency_graph(hipStream_t st, const float *prev, const flo
     return hipGetLastError();
 }
 
+// max_clique_kernel's helpers run on ONE wavefront: what they need between an LDS write and another lane's read is the order of the
+// wave's own LDS operations (s_waitcnt + no compiler motion), not a workgroup barrier - the kernel's second wavefront (the cand chain
+// of the walk, below) meets the first at its own two barriers only
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 // ------------------------------------------------------------------ wave-level bitset helpers
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src)
 {
@@ -133,6 +137,28 @@ __device__ __forceinline__ uint64_t bit_if(int lane, int v) { return (lane == (v
 // costs one vertex) and branched on the vertex with the most conflicts: first WITHOUT it (this descent is the classical
 // minimum-degree peeling and finds a near-optimal clique at once), then with it.
 // cq_solve answers "size of a maximum clique inside P0, if it exceeds `best`" and stops early at `target`.
+#ifdef NX_EXP_STATS
+__device__ unsigned long long nx_prof[24];
+__shared__ unsigned long long nx_acc[24];           // accumulated in LDS (an add without return does not stall the wave), flushed at the end
+#define NX_ADD(k, v) __hip_atomic_fetch_add(&nx_acc[k], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define NX_T0 const unsigned long long t0_ = __builtin_readcyclecounter();
+#define NX_T1(k) { if (c.lane == 0) NX_ADD(k, __builtin_readcyclecounter() - t0_); }
+#define NX_CNT(k) { if (c.lane == 0) NX_ADD(k, 1); }
+#define NX_L0 unsigned long long tl_ = __builtin_readcyclecounter();
+#define NX_L1(k) { const unsigned long long tn_ = __builtin_readcyclecounter(); if (lane == 0) NX_ADD(k, tn_ - tl_); tl_ = tn_; }
+extern "C" int roam_debug_clique_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nx_prof), sizeof(nx_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(nx_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define NX_T0
+#define NX_T1(k)
+#define NX_CNT(k)
+#define NX_L0
+#define NX_L1(k)
+#endif
 struct CqCtx {
     const uint64_t *A;          // adjacency rows (LDS or global), stride `as` words
     int as, nw, nws, lane;
@@ -162,7 +188,7 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
                 if (size + cnt <= best) { dead = true; break; }
                 if (cnt == 0) break;
                 if (lane < 16) c.sw[lane] = P;
-                __syncthreads();
+                WSYNC();
                 const int thr = best - size;                            // an improving clique needs >= thr neighbours inside P
                 uint64_t RM = 0, UN = 0, PE = 0;
                 int key = 0x7fffffff;
@@ -178,7 +204,7 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
                     if (lane == g) { RM = brm; UN = bun; PE = bpe; }
                     if (in) key = min(key, d * 2048 + (2047 - u));      // fewest neighbours = most conflicts; ties: largest index
                 }
-                __syncthreads();
+                WSYNC();
                 if (__ballot(RM != 0)) { P &= ~RM; continue; }
                 if (__ballot(UN != 0)) { R |= UN; size += bs_count(UN); P &= ~UN; continue; }
                 if (__ballot(PE != 0)) {
@@ -245,12 +271,12 @@ __device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &R
                 c.stk[((int64_t)depth * 2 + 1) * c.nws + lane] = R;
             }
             if (lane == 0) { c.lsize[depth] = (short)size; c.lv[depth] = (short)vbr; c.lstage[depth] = 0; }
-            __syncthreads();
+            WSYNC();
             continue;
         }
         if (depth < 0) return best;
         const int stage = c.lstage[depth], v = c.lv[depth], sl = c.lsize[depth];
-        __syncthreads();
+        WSYNC();
         if (stage >= 2) { depth--; continue; }
         if (lane == 0) c.lstage[depth] = (short)(stage + 1);
         const uint64_t Pl = (lane < nw) ? c.stk[((int64_t)depth * 2) * c.nws + lane] : 0ull;
@@ -340,9 +366,9 @@ __device__ int nx_seq(const CqCtx &c, const NxSet &S, uint64_t F, uint16_t *seq,
             n += __popcll(bits);
         }
     } else {
-        __syncthreads();
+        WSYNC();
         if (lane < 16) c.sw[lane] = X;
-        __syncthreads();
+        WSYNC();
         for (int ch = 0; ch * 64 <= S.mask; ch++) {
             const uint64_t ob = rl64(S.occ, ch);
             if (!ob) continue;
@@ -354,7 +380,7 @@ __device__ int nx_seq(const CqCtx &c, const NxSet &S, uint64_t F, uint16_t *seq,
             n += __popcll(bal);
         }
     }
-    __syncthreads();
+    WSYNC();
     return n;
 }
 
@@ -369,9 +395,9 @@ __device__ uint64_t nx_phase(const CqCtx &c, const uint16_t *P, int m, int mask,
     const int lane = c.lane;
     for (int i = lane; i < m; i += 64) slot[i] = (uint16_t)(P[i] & mask);
     for (;;) {
-        __syncthreads();
+        WSYNC();
         for (int s0 = lane; s0 <= mask; s0 += 64) T[s0] = 0xffffffffu;
-        __syncthreads();
+        WSYNC();
         // (atomicMin through a generic pointer to LDS raises a memory-aperture fault here: the minimum by repeated plain stores)
         for (int i0 = 0; i0 < m; i0 += 64) {
             const int i = i0 + lane;
@@ -379,10 +405,10 @@ __device__ uint64_t nx_phase(const CqCtx &c, const uint16_t *P, int m, int mask,
                 const bool want = i < m && T[slot[i]] > (uint32_t)i;
                 if (!__ballot(want)) break;
                 if (want) T[slot[i]] = (uint32_t)i;
-                __syncthreads();
+                WSYNC();
             }
         }
-        __syncthreads();
+        WSYNC();
         bool moved = false;
         for (int i = lane; i < m; i += 64) {
             const unsigned key = P[i];
@@ -411,16 +437,16 @@ __device__ uint64_t nx_phase(const CqCtx &c, const uint16_t *P, int m, int mask,
 __device__ void nx_slot_order(const CqCtx &c, const uint16_t *P, const uint16_t *slot, int m, uint64_t occ, uint16_t *P2)
 {
     const int lane = c.lane;
-    __syncthreads();
+    WSYNC();
     if (lane < 16) c.sw[lane] = occ;                                   // tables of at most 1024 slots reach this point
-    __syncthreads();
+    WSYNC();
     for (int i = lane; i < m; i += 64) {
         const int sl = slot[i], w = sl >> 6;
         int r = __popcll(c.sw[w] & ((1ull << (sl & 63)) - 1ull));
         for (int k = 0; k < w; k++) r += __popcll(c.sw[k]);
         P2[r] = P[i];
     }
-    __syncthreads();
+    WSYNC();
 }
 
 // slot of `key` in a table of at most 128 slots whose occupancy is the pair (o0, o1): everything wave-uniform, scalar ALU only
@@ -439,10 +465,9 @@ __device__ __forceinline__ int nx_probe2(uint64_t o0, uint64_t o1, int mask, int
     }
 }
 
-// nx_build for sets of at most 64 members in tables of at most 128 slots (every explicit table but a few when K <= 512): the keys sit
-// in ONE register (lane j = the j-th key inserted), an insertion is v_readlane + a dozen scalar instructions + a lane select for the
-// slot, and "re-insert in slot order" at a resize is one ds_permute by the rank of the slot.  Kept out of line: inlined into the walk
-// (three copies of the loop) the kernel needed 199 registers and the build of ROCm 7.2 produced a binary that faulted.
+// the scalar replay of a SMALL table (5 keys in 8 slots, 19 in 32): the keys sit in ONE register (lane j = the j-th key inserted), an
+// insertion is v_readlane + a dozen scalar instructions + a lane select for the slot, and "re-insert in slot order" at a resize is one
+// ds_permute by the rank of the slot.
 // one pass: keys of lanes 0..m-1 into an empty table; the lane's slot lands in sv, the occupancy in (o0, o1)
 __device__ __forceinline__ void nx_run_small(int lane, int kv, int &sv, uint64_t &o0, uint64_t &o1, int m, int mask)
 {
@@ -460,39 +485,129 @@ __device__ __forceinline__ int nx_reorder_small(int lane, int kv, int sv, uint64
     const int r = __popcll(o0 & ((1ull << (sv & 63)) - 1ull));       // (a table of <= 32 slots) rank of the lane's slot
     return __builtin_amdgcn_ds_permute((lane < m ? r : lane) << 2, kv);
 }
-__device__ __attribute__((noinline)) int nx_build_small(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab)
+// nx_build for sets of at most 128 members in tables of at most 256 slots (every explicit table there is while K <= 512).  Kept out of
+// line: inlined into the walk (three copies) the kernel needed 199 registers and the build of ROCm 7.2 produced a binary that faulted.
+//   * no two keys with the same home slot in the FINAL table => every key finds its home free whenever it is inserted: the layout is
+//     "key at key & mask" whatever the order, and the earlier tables (which only decide that order) need no replay either.  The rule
+//     for most sets of 19..76 members here (128 slots, ids below ~170: only k and k + 128 can meet).  Returns 1.
+//   * otherwise the small tables the set grew through (5 keys in 8 slots, 19 in 32) are replayed key by key on the scalar unit
+//     (nx_run_small; the keys sit in ONE register, lane j = the j-th key inserted) - or not at all: along the forced levels of the
+//     walk a child's first 19 keys are mostly its parent's, so the outcome of the two small tables is remembered per set (ci = 0 the
+//     subg chain, 1 the cand chain, -1 neither) under the 19 keys that produced it;
+//   * and the FINAL table is filled by all keys at once (round 5; it was one key at a time, ~100 cycles each on a lone wave, and the
+//     LDS fixed point of nx_phase for more than 64 keys: 25 us a set): T[s] = the earliest key that wants slot s (ds_min), every key
+//     walks its probe sequence to the first slot no EARLIER key holds, until nothing moves - the fixed point is the sequential
+//     result (see nx_phase), the rounds needed are the longest chain of displacements: two or three at these load factors.
+__shared__ uint32_t nx_T[128];
+__shared__ uint16_t nx_ck[2][32], nx_cv[2][32];      // [ci][0..18] the keys / the outcome, [ci][19] of nx_ck: 1 = valid
+__device__ __forceinline__ int nx_probe_T(int key, int idx, int mask)
+{
+    unsigned perturb = (unsigned)key, i0 = (unsigned)key & (unsigned)mask;
+    for (;;) {
+        const int lim = (i0 + 9 <= (unsigned)mask) ? 9 : 0;
+        for (int j = 0; j <= lim; j++) if (nx_T[i0 + j] >= (uint32_t)idx) return (int)i0 + j;
+        perturb >>= 5;
+        i0 = (i0 * 5 + 1 + perturb) & (unsigned)mask;
+    }
+}
+__device__ __attribute__((noinline)) int nx_build_fast(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab, int ci_)
 {
     // (arguments of an out-of-line function arrive in vector registers: say that these are wave-uniform, or every loop below
     // becomes a divergent one and v_readlane a waterfall)
-    const int n = __builtin_amdgcn_readfirstlane(n_), size = __builtin_amdgcn_readfirstlane(size_);
+    const int n = __builtin_amdgcn_readfirstlane(n_), size = __builtin_amdgcn_readfirstlane(size_), ci = __builtin_amdgcn_readfirstlane(ci_);
     const bool copy = __builtin_amdgcn_readfirstlane((int)copy_) != 0;
-    int kv = lane < n ? (int)seq[lane] : 0, sv = 0;
-    uint64_t o0 = 0, o1 = 0;
-    // No two keys with the same home slot in the FINAL table => every key finds its home free whenever it is inserted: the layout is
-    // "key at key & mask" whatever the order, and the earlier tables (which only decide that order) need no replay either.  The rule
-    // for most sets of 19..76 members here (128 slots, ids below ~170: only k and k + 128 can meet).
-    {
-        __shared__ uint32_t hb[4];
-        if (lane < 4) hb[lane] = 0u;
-        __syncthreads();
-        const int h = kv & (size - 1);
-        if (lane < n) atomicOr(&hb[h >> 5], 1u << (h & 31));
-        __syncthreads();
-        const uint64_t b0 = (uint64_t)hb[0] | ((uint64_t)hb[1] << 32), b1 = (uint64_t)hb[2] | ((uint64_t)hb[3] << 32);
-        __syncthreads();
-        if (__popcll(b0) + __popcll(b1) == n) {
-            if (lane < n) tab[h] = (uint16_t)kv;
-            *occ_out = lane == 0 ? b0 : (lane == 1 ? b1 : 0ull);
-            return 1;
+    NX_L0
+    int k0 = lane < n ? (int)seq[lane] : 0;
+    const int k1 = lane + 64 < n ? (int)seq[lane + 64] : 0;
+    const int kin = k0;
+    const bool grows = !copy && n >= 5 && size > 8, big = grows && n >= 19 && size > 32;
+    int s0 = 0, s1 = 0;
+    bool first = true, perfect = false;
+    uint64_t l0 = 0, l1 = 0;                                            // slots taken by displaced keys
+    uint32_t t0 = 0xffffffffu, t1 = 0xffffffffu;
+    for (;;) {
+        // The final table (first of all: with no two keys at the same home there is nothing else to do): keys 0..n-1 (lane j and, from
+        // 64 on, lane j - 64 of the second register) into size empty slots, in that order.
+        // T[s] = the earliest key whose HOME is s.  A key that finds its home taken - by an earlier key with the same home, or by a
+        // displaced key that landed there first - is "displaced"; everybody else sits at home.  The displaced keys are few and are
+        // placed one after the other in insertion order with wave-uniform arithmetic: slot s is taken when key d arrives iff an
+        // earlier key has its home there (T[s] < d: that key sits there, or whoever displaced it came even earlier - one vector
+        // compare gives all those slots as a bit mask) or an earlier displaced key landed there; a LATER home key found in the slot
+        // taken is displaced in turn.
+        const int m = n, msk = size - 1;
+        const bool a0 = lane < m, a1 = lane + 64 < m;
+        s0 = k0 & msk; s1 = k1 & msk;
+        l0 = 0; l1 = 0;
+        WSYNC();
+        nx_T[lane] = 0xffffffffu;
+        if (msk > 63) nx_T[lane + 64] = 0xffffffffu;
+        WSYNC();
+        if (a0) atomicMin(&nx_T[s0], (uint32_t)lane);
+        if (a1) atomicMin(&nx_T[s1], (uint32_t)(lane + 64));
+        WSYNC();
+        t0 = nx_T[lane];
+        t1 = msk > 63 ? nx_T[lane + 64] : 0xffffffffu;
+        uint64_t p0 = __ballot(a0 && nx_T[s0] != (uint32_t)lane), p1 = __ballot(a1 && nx_T[s1] != (uint32_t)(lane + 64));
+        if (first) {
+            first = false;
+            NX_L1(16)
+            if (!(p0 | p1)) { perfect = true; break; }
+            if (grows) {
+                bool hit = false;
+                if (big && ci >= 0) hit = !__ballot(lane < 19 && nx_ck[ci][lane] != (uint16_t)k0) && nx_ck[ci][19] == 1;
+#ifdef NX_EXP_STATS
+                if (lane == 0 && big) NX_ADD(hit ? 15 : 10, 1);
+#endif
+                if (hit) { if (lane < 19) k0 = nx_cv[ci][lane]; }
+                else {
+                    // (the small tables key by key on the scalar unit: half of their keys are displaced, which the scheme of the
+                    // final table does not like - measured: 6.1 k cycles per set against 4.3 k this way)
+                    int sv = 0;
+                    uint64_t q0, q1;
+                    nx_run_small(lane, k0, sv, q0, q1, 5, 7); k0 = nx_reorder_small(lane, k0, sv, q0, 5);
+                    if (big) {
+                        nx_run_small(lane, k0, sv, q0, q1, 19, 31); k0 = nx_reorder_small(lane, k0, sv, q0, 19);
+                        if (ci >= 0) { if (lane < 19) { nx_ck[ci][lane] = (uint16_t)kin; nx_cv[ci][lane] = (uint16_t)k0; } if (lane == 19) nx_ck[ci][19] = 1; }
+                    }
+                }
+                NX_L1(17)
+                continue;
+            }
         }
+        while (p0 | p1) {
+#ifdef NX_EXP_STATS
+            if (lane == 0) NX_ADD(9, 1);
+#endif
+            int d;
+            if (p0) { d = __ffsll((long long)p0) - 1; p0 &= p0 - 1; } else { d = 64 + __ffsll((long long)p1) - 1; p1 &= p1 - 1; }
+            const int key = d < 64 ? __builtin_amdgcn_readlane(k0, d) : __builtin_amdgcn_readlane(k1, d - 64);
+            const uint64_t o0 = __ballot(t0 < (uint32_t)d) | l0, o1 = __ballot(t1 < (uint32_t)d) | l1;      // (slots past the table: INF, never "taken" - and never probed)
+            unsigned perturb = (unsigned)key, i = (unsigned)key & (unsigned)msk;
+            int got;
+            for (;;) {
+                const int lim = (i + 9 <= (unsigned)msk) ? 9 : 0;
+                const int sh = (int)(i & 63);
+                uint64_t win = ((i >> 6) ? o1 : o0) >> sh;
+                if (!(i >> 6) && sh + lim >= 64) win |= o1 << (64 - sh);
+                const uint64_t fr = ~win & ((2ull << lim) - 1ull);
+                if (fr) { got = (int)i + __ffsll((long long)fr) - 1; break; }
+                perturb >>= 5;
+                i = (i * 5 + 1 + perturb) & (unsigned)msk;
+            }
+            const uint32_t tv = got < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)t0, got) : (uint32_t)__builtin_amdgcn_readlane((int)t1, got - 64);
+            if (tv != 0xffffffffu) { if (tv < 64u) p0 |= 1ull << tv; else p1 |= 1ull << (tv - 64u); }           // its home key comes later: displaced
+            if (got < 64) l0 |= 1ull << got; else l1 |= 1ull << (got - 64);
+            if (d < 64) s0 = lane == d ? got : s0; else s1 = lane == d - 64 ? got : s1;
+        }
+        NX_L1(18)
+        break;
     }
-    // the tables the set goes through: 5 keys in 8 slots, 19 in 32, then all of them in the final one
-    if (!copy && n >= 5 && size > 8) { nx_run_small(lane, kv, sv, o0, o1, 5, 7); kv = nx_reorder_small(lane, kv, sv, o0, 5); }
-    if (!copy && n >= 19 && size > 32) { nx_run_small(lane, kv, sv, o0, o1, 19, 31); kv = nx_reorder_small(lane, kv, sv, o0, 19); }
-    nx_run_small(lane, kv, sv, o0, o1, n, size - 1);
-    if (lane < n) tab[sv] = (uint16_t)kv;
-    *occ_out = lane == 0 ? o0 : (lane == 1 ? o1 : 0ull);
-    return 0;
+    if (lane < n) tab[s0] = (uint16_t)k0;
+    if (lane + 64 < n) tab[s1] = (uint16_t)k1;
+    const uint64_t b0 = __ballot(t0 != 0xffffffffu && lane < size) | l0, b1 = __ballot(t1 != 0xffffffffu) | l1;
+    *occ_out = lane == 0 ? b0 : lane == 1 ? b1 : 0ull;
+    NX_L1(19)
+    return perfect ? 1 : 0;
 }
 
 // table of a set built by inserting seq[0..n) one by one (copy = false: growth 8 -> 32 -> 128 -> 512 -> 2048, set_add_entry
@@ -510,12 +625,18 @@ __device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq
     D.ident = true;
 #endif
     if (D.ident) return;
-    if (size <= 128 && n <= 64) {
+    NX_CNT(8)
+    if (size <= 128 && n <= 128) {
         uint64_t o;
-        const int pf = nx_build_small(c.lane, &o, seq, n, size, copy, tab);
-        __syncthreads();
+        int pf;
+        const int ci = (tab == L.tab[0] || tab == L.tab[1]) ? 0 : (tab == L.tab[2] || tab == L.tab[3]) ? 1 : -1;
+        { NX_T0 pf = nx_build_fast(c.lane, &o, seq, n, size, copy, tab, ci); NX_T1(13) }
+        WSYNC();
         D.occ = o;
         D.perfect = __builtin_amdgcn_readfirstlane(pf) != 0;
+#ifdef NX_EXP_STATS
+        if (D.perfect) NX_CNT(12)
+#endif
         return;
     }
     const uint16_t *P = seq;
@@ -529,7 +650,7 @@ __device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq
             // list of this phase: the previous phase's keys in slot order + the keys inserted since
             uint16_t *cur = (P == bufa) ? bufb : bufa;
             for (int i = lane; i < m; i += 64) cur[i] = (i < have) ? P[i] : seq[i];
-            __syncthreads();
+            WSYNC();
             const uint64_t occ = nx_phase(c, cur, m, msk[ph], L.slot, L.T);
             uint16_t *nxt = (cur == bufa) ? bufb : bufa;
             nx_slot_order(c, cur, L.slot, m, occ, nxt);
@@ -538,13 +659,13 @@ __device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq
         if (have) {
             uint16_t *cur = (P == bufa) ? bufb : bufa;
             for (int i = lane; i < n; i += 64) cur[i] = (i < have) ? P[i] : seq[i];
-            __syncthreads();
+            WSYNC();
             P = cur;
         }
     }
     const uint64_t occ = nx_phase(c, P, n, size - 1, L.slot, L.T);
     for (int i = lane; i < n; i += 64) tab[L.slot[i]] = P[i];
-    __syncthreads();
+    WSYNC();
     D.occ = occ;
 }
 
@@ -558,8 +679,8 @@ __device__ void nx_filter_build(const CqCtx &c, NxLds &L, NxSet &D, const NxSet 
     // the common case needs no replay at all: every key below the table size => each key in its own slot, whatever the order
     const int n0 = bs_count(X), mk0 = bs_last(X);
     if (mk0 < nx_incr_size(n0)) { D.used = n0; D.tab = tab; D.occ = 0; D.mask = nx_incr_size(n0) - 1; D.ident = true; D.perfect = false; return; }
-    int maxkey;
-    const int n = nx_seq(c, ITER, F, L.seq, maxkey);
+    int maxkey, n;
+    { NX_T0 n = nx_seq(c, ITER, F, L.seq, maxkey); NX_T1(14) }
     nx_build(c, L, D, L.seq, n, maxkey, false, tab);
 }
 
@@ -591,9 +712,9 @@ __device__ void nx_and_adj(const CqCtx &c, NxLds &L, NxSet &D, const NxSet &S, i
 __device__ int nx_pivot(const CqCtx &c, const NxSet &SG, uint64_t candbits)
 {
     const int lane = c.lane;
-    __syncthreads();
+    WSYNC();
     if (lane < 16) c.sw[lane] = candbits;
-    __syncthreads();
+    WSYNC();
     int best = -1;                                                      // (count << 12) | (4095 - position), then the key
     int bestu = 0;
     const int chunks = SG.ident ? c.nw : (SG.mask >> 6) + 1;
@@ -611,7 +732,7 @@ __device__ int nx_pivot(const CqCtx &c, const NxSet &SG, uint64_t candbits)
     const int m = wave_max_i(best);
     const uint64_t who = __ballot(best == m);
     const int src = __ffsll((long long)who) - 1;
-    __syncthreads();
+    WSYNC();
     return __builtin_amdgcn_readlane(bestu, src);
 }
 
@@ -624,7 +745,7 @@ __device__ void nx_sub_adj(const CqCtx &c, NxLds &L, NxSet &E, const NxSet &CD, 
         if (CD.used >= 5) while (size <= 2 * CD.used) size <<= 1;
         if (size - 1 == CD.mask) {                                      // same table size: slot-for-slot copy
             E = CD; E.tab = L.tab[5];
-            if (!CD.ident) { for (int i = lane; i <= CD.mask; i += 64) L.tab[5][i] = CD.tab[i]; __syncthreads(); }
+            if (!CD.ident) { for (int i = lane; i <= CD.mask; i += 64) L.tab[5][i] = CD.tab[i]; WSYNC(); }
         } else {
             int maxkey;
             const int n = nx_seq(c, CD, ~0ull, L.seq, maxkey);
@@ -662,20 +783,23 @@ __device__ int nx_pop(const CqCtx &c, NxSet &E)
     return q;
 }
 
-// ext_u of at most four members out of an ascending cand (by far the commonest case: the pivot is adjacent to almost everything): the
-// 8-slot table is replayed on the scalar unit and the members come back packed in pop order, 16 bits each.  false: not this case.
-__device__ __forceinline__ bool nx_sub_adj_tiny(const CqCtx &c, const NxSet &CD, uint64_t row, int deg, uint64_t &elist, int &en)
+// ext_u of at most four members (by far the commonest case: the pivot is adjacent to almost everything): the 8-slot table is replayed
+// on the scalar unit and the members come back packed in pop order, 16 bits each.  cand iterates in ascending order (ident) or in the
+// order of its explicit table (nx_seq lists the few members that are left).  false: not this case.
+__device__ __forceinline__ bool nx_sub_adj_tiny(const CqCtx &c, NxLds &L, const NxSet &CD, uint64_t row, int deg, uint64_t &elist, int &en)
 {
-    if (!CD.ident || (CD.used >> 2) > deg) return false;
+    if ((CD.used >> 2) > deg) return false;
     uint64_t X = CD.live & ~row;
     const int n = bs_count(X);
     if (n > 4) return false;
+    if (!CD.ident) { int mk; nx_seq(c, CD, ~row, L.seq, mk); }
     unsigned occ = 0;
     unsigned e0 = ~0u, e1 = ~0u, e2 = ~0u, e3 = ~0u;                   // (slot << 16) | key; unused entries sort to the end
 #define NX_TINY_INS(e, k)                                                                                               \
     if (k < n) {                                                                                                        \
-        const int key = bs_first(X);                                                                                    \
-        X &= ~bit_if(c.lane, key);                                                                                      \
+        int key;                                                                                                        \
+        if (CD.ident) { key = bs_first(X); X &= ~bit_if(c.lane, key); }                                                 \
+        else key = __builtin_amdgcn_readfirstlane((int)L.seq[k]);                                                       \
         unsigned perturb = (unsigned)key, i = (unsigned)key & 7u;                                                       \
         while ((occ >> i) & 1u) { perturb >>= 5; i = (i * 5 + 1 + perturb) & 7u; }     /* mask 7: no linear probes */     \
         occ |= 1u << i;                                                                                                 \
@@ -719,9 +843,9 @@ __device__ void nx_bulk(const CqCtx &c, NxSet &subg, NxSet &cand, uint64_t &RF, 
     const bool sp = !subg.ident && subg.perfect && subg.mask >= 127, cp = !cand.ident && cand.perfect && cand.mask >= 127;
     if (!(subg.ident || sp) || !(cand.ident || cp) || cand.used < 2) return;
     const int lane = c.lane, nw = c.nw;
-    __syncthreads();
+    WSYNC();
     if (lane < 16) c.sw[lane] = cand.live;
-    __syncthreads();
+    WSYNC();
     uint64_t T = 0;
     const int full = cand.used - 1;
     for (int ch = 0; ch < nw; ch++) {
@@ -738,7 +862,7 @@ __device__ void nx_bulk(const CqCtx &c, NxSet &subg, NxSet &cand, uint64_t &RF, 
         if (lane == ch) T = b;
         if (__ballot(in && d > full)) { T = 0; break; }                 // an excluded vertex adjacent to ALL of cand is the pivot: nothing to skip
     }
-    __syncthreads();
+    WSYNC();
     const int hws = sp ? ((subg.mask + 1) >> 6) - 1 : 0xffff;           // iteration order of subg: by (word & hws) * 64 + bit
     bool folded = false;
     for (;;) {
@@ -782,6 +906,8 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
     cand.mask = (Kb < 5 ? 8 : Kb < 19 ? 32 : Kb < 77 ? 128 : Kb < 307 ? 512 : 2048) - 1;
     subg = cand; subg.tab = L.tab[0];                                                                          // cand.copy(): likewise
     RF = 0;
+    if (lane < 2) nx_ck[lane][19] = 0;                                  // nothing remembered yet (nx_build_fast)
+    WSYNC();
     int size = 0;
     bool entered = true;                                                // a node was just entered: its pivot and ext_u are due
     // (every helper appears ONCE in this loop: with the set-up of a node written out before the loop as well, the kernel grew past
@@ -798,20 +924,23 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
 #ifndef NX_EXP_NOSHORT
             if (cand.used == omega - size) { RF |= cand.live; return true; }
 #endif
+            NX_CNT(6)
 #ifndef NX_EXP_NOBULK
-            nx_bulk(c, subg, cand, RF, size);
+            { NX_T0 nx_bulk(c, subg, cand, RF, size); NX_T1(0) }
 #endif
-            const int pu = nx_pivot(c, subg, cand.live);
+            int pu;
+            { NX_T0 pu = nx_pivot(c, subg, cand.live); NX_T1(1) }
             const uint64_t prow = (lane < nw) ? c.A[(int64_t)pu * c.as + lane] : 0ull;
             const int pdeg = bs_count(prow);
-            if (!nx_sub_adj_tiny(c, cand, prow, pdeg, elist, en)) { en = -1; nx_sub_adj(c, L, ext, cand, prow, pdeg); }
+            { NX_T0 if (!nx_sub_adj_tiny(c, L, cand, prow, pdeg, elist, en)) { en = -1; nx_sub_adj(c, L, ext, cand, prow, pdeg); } NX_T1(2) }
         }
+        NX_CNT(7)
         int q;
         if (en >= 0) {
             q = en ? (int)(elist & 0xffffull) : -1;
             elist >>= 16; en--;
         } else
-            q = nx_pop(c, ext);
+            { NX_T0 q = nx_pop(c, ext); NX_T1(3) }
         if (q < 0) return false;                                        // cannot happen while the existence answers are exact
         const uint64_t bq = bit_if(lane, q);
         cand.live &= ~bq;                                               // cand.remove(q): a dummy stays in its slot
@@ -835,7 +964,8 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
 #ifdef NX_EXP_STATS
             c.nq++;
 #endif
-            const int got = cq_solve(c, Cq, need - 1, need, RQ);
+            int got;
+            { NX_T0 got = cq_solve(c, Cq, need - 1, need, RQ); NX_T1(4) }
             if (!c.complete) return false;
             if (got >= need) { ok = true; WIT = QB | RQ; }
         }
@@ -850,7 +980,7 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
         for (int which = 0; which < 2; which++) {
             const NxSet &S = which ? cand : subg;
             NxSet &D = which ? ncand : nsub;
-            nx_and_adj(c, L, D, S, S.used, row, deg, L.tab[2 * which + (cur ^ 1)]);
+            { NX_T0 nx_and_adj(c, L, D, S, S.used, row, deg, L.tab[2 * which + (cur ^ 1)]); NX_T1(5) }
         }
         subg = nsub; cand = ncand; cur ^= 1;
         RF = QB; size = s1;
@@ -890,11 +1020,15 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
         }
         c.A = adj_l; c.as = nw;
     } else { c.A = Ag; c.as = nws; }
-    __syncthreads();
+    WSYNC();
     c.nw = nw; c.nws = nws; c.lane = lane; c.sw = sw;
     c.stk = stack_g + (int64_t)b * (kstride + 2) * 2 * nws;
     c.lsize = lsize; c.lv = lv; c.lstage = lstage;
     c.nodes = 0; c.node_limit = node_limit; c.complete = true;
+#ifdef NX_EXP_STATS
+    if (lane < 24) nx_acc[lane] = 0;
+    WSYNC();
+#endif
 
     uint64_t ALL = 0;                               // all-vertices set in word-per-lane layout
     if (lane < nw) {
@@ -925,17 +1059,19 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
         L.slot = L.seq3 + (K + 2);
         L.T = reinterpret_cast<uint32_t *>(L.slot + (K + 2) + ((6 * L.ts + 4 * (K + 2)) & 1));
         uint64_t RF = 0;
-        if (nx_walk(c, L, Kb, ALL, omega, WIT, RF)) REC = RF;
+        { NX_T0 if (nx_walk(c, L, Kb, ALL, omega, WIT, RF)) REC = RF; NX_T1(11) }
     }
 
     // ---- emit
     if (lane < 16) sw[lane] = REC;
-    __syncthreads();
+    WSYNC();
     for (int u = lane; u < Kb; u += 64) mask[u] = (uint8_t)((sw[u >> 6] >> (u & 63)) & 1ull);
     for (int u = Kb + lane; u < kstride && u < K; u += 64) mask[u] = 0;
     const int cnt = bs_count(REC);
     if (lane == 0) { n_in[b] = cnt; flags[b] = c.complete ? 1 : 0; }
 #ifdef NX_EXP_STATS
+    WSYNC();
+    if (lane < 24) atomicAdd(&nx_prof[lane], nx_acc[lane]);
     if (lane == 0) flags[b] |= (min(c.nq, 255) << 8) | ((int)min((c.nodes - c.nodes1), 32767ll) << 16);
     if (lane == 0) n_in[b] = cnt | ((int)min(c.nodes1, 32767ll) << 16);
 #endif
