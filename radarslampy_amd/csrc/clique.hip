@@ -162,6 +162,7 @@ extern "C" int roam_debug_clique_prof(unsigned long long *out, int reset)
 struct CqCtx {
     const uint64_t *A;          // adjacency rows (LDS or global), stride `as` words
     int as, nw, nws, lane;
+    int wv;                     // 0: the wavefront that runs the search, 1: its helper (the cand chain of the walk)
     uint64_t *sw;               // 16 words of LDS: the current set broadcast to all lanes
     uint64_t *stk;              // global scratch: 2 * nws words per level
     short *lsize, *lv, *lstage; // per level: |R|, branching vertex, stage
@@ -172,7 +173,7 @@ struct CqCtx {
 #endif
 };
 
-__device__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &REC)
+__device__ __forceinline__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &REC)
 {
     const int lane = c.lane, nw = c.nw;
     uint64_t P = P0, R = 0;
@@ -316,7 +317,9 @@ struct NxSet {
     bool ident;
     bool perfect;       // explicit layout in which every key sits at its home slot key & mask (no key was ever displaced)
 };
-struct NxLds { uint16_t *tab[6], *seq, *seq2, *seq3, *slot; uint32_t *T; int ts; };
+// what the wavefront of the search hands to its helper at a descent (cand, adj[q]) and gets back (cand & adj[q]): see nx_walk
+struct NxMail { uint64_t live[64], occ[64], row[64]; int cmd, used, mask, ident, perfect, srctab, dsttab, deg; };
+struct NxLds { uint16_t *tab[6], *seq, *seq2, *seq3, *slot; uint32_t *T; int ts; NxMail *mail; };
 
 __host__ __device__ inline int nx_table_slots(int K)
 {
@@ -324,9 +327,29 @@ __host__ __device__ inline int nx_table_slots(int K)
     while (ts * 2 < K && ts < 512) ts *= 2;
     return ts;
 }
+__host__ __device__ inline size_t nx_scratch_bytes(int K)       // seq, seq2, seq3, slot + T of one wavefront
+{
+    return ((4 * (size_t)(K + 2)) * sizeof(uint16_t) + (size_t)nx_table_slots(K) * sizeof(uint32_t) + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t nx_lds_bytes(int K)
 {
-    return (((size_t)6 * nx_table_slots(K) + 4 * (size_t)(K + 2)) * sizeof(uint16_t) + (size_t)nx_table_slots(K) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return (((size_t)7 * nx_table_slots(K) * sizeof(uint16_t) + 15) & ~(size_t)15) + 2 * nx_scratch_bytes(K) + sizeof(NxMail);
+}
+// the walk's LDS: seven tables (0/1 the subg chain, 2/3 the cand chain, 4 adj[q] of wavefront 0, 5 ext_u, 6 adj[q] of wavefront 1), the
+// lists of each wavefront, the mailbox
+__device__ inline void nx_lds_carve(NxLds &L, unsigned char *mem, int K, int wv)
+{
+    L.ts = nx_table_slots(K);
+    uint16_t *base = reinterpret_cast<uint16_t *>(mem);
+    for (int t = 0; t < 6; t++) L.tab[t] = base + t * L.ts;
+    if (wv) L.tab[4] = L.tab[5] = base + 6 * L.ts;
+    unsigned char *scr = mem + (((size_t)7 * L.ts * sizeof(uint16_t) + 15) & ~(size_t)15) + (size_t)wv * nx_scratch_bytes(K);
+    L.seq = reinterpret_cast<uint16_t *>(scr);
+    L.seq2 = L.seq + (K + 2);
+    L.seq3 = L.seq2 + (K + 2);
+    L.slot = L.seq3 + (K + 2);
+    L.T = reinterpret_cast<uint32_t *>(L.slot + (K + 2));
+    L.mail = reinterpret_cast<NxMail *>(mem + (((size_t)7 * L.ts * sizeof(uint16_t) + 15) & ~(size_t)15) + 2 * nx_scratch_bytes(K));
 }
 
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int src)
@@ -498,9 +521,9 @@ __device__ __forceinline__ int nx_reorder_small(int lane, int kv, int sv, uint64
 //     LDS fixed point of nx_phase for more than 64 keys: 25 us a set): T[s] = the earliest key that wants slot s (ds_min), every key
 //     walks its probe sequence to the first slot no EARLIER key holds, until nothing moves - the fixed point is the sequential
 //     result (see nx_phase), the rounds needed are the longest chain of displacements: two or three at these load factors.
-__shared__ uint32_t nx_T[128];
+__shared__ uint32_t nx_Tw[2][128];                  // one per wavefront
 __shared__ uint16_t nx_ck[2][32], nx_cv[2][32];      // [ci][0..18] the keys / the outcome, [ci][19] of nx_ck: 1 = valid
-__device__ __forceinline__ int nx_probe_T(int key, int idx, int mask)
+__device__ __forceinline__ int nx_probe_T(const uint32_t *nx_T, int key, int idx, int mask)
 {
     unsigned perturb = (unsigned)key, i0 = (unsigned)key & (unsigned)mask;
     for (;;) {
@@ -510,8 +533,9 @@ __device__ __forceinline__ int nx_probe_T(int key, int idx, int mask)
         i0 = (i0 * 5 + 1 + perturb) & (unsigned)mask;
     }
 }
-__device__ __attribute__((noinline)) int nx_build_fast(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab, int ci_)
+__device__ __attribute__((noinline)) int nx_build_fast(int lane, uint64_t *occ_out, const uint16_t *seq, int n_, int size_, bool copy_, uint16_t *tab, int ci_, int wv_)
 {
+    uint32_t *nx_T = nx_Tw[__builtin_amdgcn_readfirstlane(wv_)];
     // (arguments of an out-of-line function arrive in vector registers: say that these are wave-uniform, or every loop below
     // becomes a divergent one and v_readlane a waterfall)
     const int n = __builtin_amdgcn_readfirstlane(n_), size = __builtin_amdgcn_readfirstlane(size_), ci = __builtin_amdgcn_readfirstlane(ci_);
@@ -630,7 +654,7 @@ __device__ void nx_build(const CqCtx &c, NxLds &L, NxSet &D, const uint16_t *seq
         uint64_t o;
         int pf;
         const int ci = (tab == L.tab[0] || tab == L.tab[1]) ? 0 : (tab == L.tab[2] || tab == L.tab[3]) ? 1 : -1;
-        { NX_T0 pf = nx_build_fast(c.lane, &o, seq, n, size, copy, tab, ci); NX_T1(13) }
+        { NX_T0 pf = nx_build_fast(c.lane, &o, seq, n, size, copy, tab, ci, c.wv); NX_T1(13) }
         WSYNC();
         D.occ = o;
         D.perfect = __builtin_amdgcn_readfirstlane(pf) != 0;
@@ -894,8 +918,32 @@ __device__ void nx_bulk(const CqCtx &c, NxSet &subg, NxSet &cand, uint64_t &RF, 
     }
 }
 
+// the second wavefront of the workgroup: cand & adj[q] of every descent of the walk, until told to leave (cmd 0)
+__device__ __forceinline__ void nx_helper(CqCtx &c, NxLds &L)
+{
+    const int lane = c.lane;
+    NxMail *mb = L.mail;
+    for (;;) {
+        __syncthreads();
+        if (mb->cmd == 0) return;
+        NxSet S, D;
+        S.live = mb->live[lane]; S.occ = mb->occ[lane];
+        S.used = mb->used; S.mask = mb->mask; S.ident = mb->ident != 0; S.perfect = mb->perfect != 0;
+        S.tab = L.tab[mb->srctab];
+        const uint64_t row = mb->row[lane];
+        const int deg = mb->deg;
+        uint16_t *dst = L.tab[mb->dsttab];
+        WSYNC();
+        { NX_T0 nx_and_adj(c, L, D, S, S.used, row, deg, dst); NX_T1(21) }
+        mb->live[lane] = D.live; mb->occ[lane] = D.occ;
+        if (lane == 0) { mb->used = D.used; mb->mask = D.mask; mb->ident = D.ident; mb->perfect = D.perfect; }
+        __syncthreads();
+    }
+}
+
 // RF = the first clique of size omega in networkx.find_cliques order.  false: the bounded searches ran out of nodes.
-__device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uint64_t WIT, uint64_t &RF)
+template <bool TWO>
+__device__ __forceinline__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uint64_t WIT, uint64_t &RF)
 {
     const int lane = c.lane, nw = c.nw;
     NxSet subg, cand, ext;
@@ -973,14 +1021,30 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
 #ifndef NX_EXP_NOSHORT
         if (ncq == need) { RF = QB | Cq; return true; }                 // (the same one level earlier: no child sets to build)
 #endif
-        // descend: subg_q = subg & adj[q], cand_q = cand & adj[q]
+        // descend: subg_q = subg & adj[q], cand_q = cand & adj[q] - two independent replays, the second one on the helper wavefront
+        // (round 5: a lone wavefront issues an instruction every ~7 cycles, and the two sets were 2/3 of a level)
         const int deg = bs_count(row);
         NxSet nsub, ncand;
+        if (TWO) {
+            NxMail *mb = L.mail;
+            mb->live[lane] = cand.live; mb->occ[lane] = cand.occ; mb->row[lane] = row;
+            if (lane == 0) {
+                mb->cmd = 1; mb->used = cand.used; mb->mask = cand.mask; mb->ident = cand.ident; mb->perfect = cand.perfect;
+                mb->srctab = 2 + cur; mb->dsttab = 2 + (cur ^ 1); mb->deg = deg;
+            }
+            __syncthreads();                                            // the helper starts (nx_helper)
+            { NX_T0 nx_and_adj(c, L, nsub, subg, subg.used, row, deg, L.tab[cur ^ 1]); NX_T1(5) }
+            { NX_T0 __syncthreads(); NX_T1(20) }                        // ... and is done
+            ncand.live = mb->live[lane]; ncand.occ = mb->occ[lane];
+            ncand.used = mb->used; ncand.mask = mb->mask; ncand.ident = mb->ident != 0; ncand.perfect = mb->perfect != 0;
+            ncand.tab = L.tab[2 + (cur ^ 1)];
+        } else {
 #pragma nounroll
-        for (int which = 0; which < 2; which++) {
-            const NxSet &S = which ? cand : subg;
-            NxSet &D = which ? ncand : nsub;
-            { NX_T0 nx_and_adj(c, L, D, S, S.used, row, deg, L.tab[2 * which + (cur ^ 1)]); NX_T1(5) }
+            for (int which = 0; which < 2; which++) {
+                const NxSet &S = which ? cand : subg;
+                NxSet &D = which ? ncand : nsub;
+                { NX_T0 nx_and_adj(c, L, D, S, S.used, row, deg, L.tab[2 * which + (cur ^ 1)]); NX_T1(5) }
+            }
         }
         subg = nsub; cand = ncand; cur ^= 1;
         RF = QB; size = s1;
@@ -988,7 +1052,8 @@ __device__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL, int omega, uin
     }
 }
 
-__global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restrict__ adj_g,
+template <bool TWO>
+__global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64_t *__restrict__ adj_g,
                                                         const int32_t *__restrict__ count, int K, int kstride,
                                                         int nws, long long node_limit,
                                                         uint64_t *__restrict__ stack_g,
@@ -996,11 +1061,11 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
                                                         int32_t *__restrict__ n_in, int32_t *__restrict__ flags)
 {
     extern __shared__ __align__(16) unsigned char cq_smem[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Kb = count ? min(count[b], K) : K;
     uint8_t *mask = mask_out + (int64_t)b * kstride;
     if (Kb <= 0) {
-        if (lane == 0) { n_in[b] = 0; flags[b] = 1; }
+        if (threadIdx.x == 0) { n_in[b] = 0; flags[b] = 1; }
         return;
     }
     const int nw = (Kb + 63) >> 6;                 // active words per bitset
@@ -1008,23 +1073,35 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
     short *lsize = reinterpret_cast<short *>(cq_smem);
     short *lv = lsize + (K + 2), *lstage = lv + (K + 2);
     uint64_t *sw = reinterpret_cast<uint64_t *>(cq_smem + ((3 * sizeof(short) * (K + 2) + 15) & ~(size_t)15));
-    unsigned char *nx_mem = reinterpret_cast<unsigned char *>(sw + 16);        // the walk's tables and lists (nx_lds_bytes)
+    unsigned char *nx_mem = reinterpret_cast<unsigned char *>(sw + 32);        // (16 words per wavefront) the walk's tables and lists (nx_lds_bytes)
     uint64_t *adj_l = reinterpret_cast<uint64_t *>(nx_mem + nx_lds_bytes(K));
     const uint64_t *Ag = adj_g + (int64_t)b * kstride * nws;
     const bool use_lds = (Kb * nw <= CQ_LDS_ADJ_WORDS);
     CqCtx c;
     if (use_lds) {
-        for (int i = lane; i < Kb * nw; i += 64) {
-            const int r = i / nw, w = i - r * nw;
-            adj_l[i] = Ag[(int64_t)r * nws + w];
-        }
+        if (wv == 0)
+            for (int i = lane; i < Kb * nw; i += 64) {
+                const int r = i / nw, w = i - r * nw;
+                adj_l[i] = Ag[(int64_t)r * nws + w];
+            }
         c.A = adj_l; c.as = nw;
     } else { c.A = Ag; c.as = nws; }
     WSYNC();
-    c.nw = nw; c.nws = nws; c.lane = lane; c.sw = sw;
+    c.nw = nw; c.nws = nws; c.lane = lane; c.wv = wv; c.sw = sw + 16 * wv;
     c.stk = stack_g + (int64_t)b * (kstride + 2) * 2 * nws;
     c.lsize = lsize; c.lv = lv; c.lstage = lstage;
     c.nodes = 0; c.node_limit = node_limit; c.complete = true;
+    // The workgroup is two wavefronts.  The first runs the search; the second waits at the workgroup barrier for the cand chain of the
+    // walk's descents (nx_helper) and leaves when the first says so.  They meet at those barriers ONLY - everything else in this file
+    // synchronises a wavefront with itself (WSYNC).
+    if (TWO && wv == 1) {
+        NxLds L1;
+        nx_lds_carve(L1, nx_mem, K, 1);
+        nx_helper(c, L1);
+        return;
+    }
+    NxLds L;
+    nx_lds_carve(L, nx_mem, K, 0);
 #ifdef NX_EXP_STATS
     if (lane < 24) nx_acc[lane] = 0;
     WSYNC();
@@ -1049,17 +1126,12 @@ __global__ __launch_bounds__(64) void max_clique_kernel(const uint64_t *__restri
 #else
     if (c.complete && omega > 0) {
 #endif
-        NxLds L;
-        L.ts = nx_table_slots(K);
-        uint16_t *base = reinterpret_cast<uint16_t *>(nx_mem);
-        for (int t = 0; t < 6; t++) L.tab[t] = base + t * L.ts;
-        L.seq = base + 6 * L.ts;
-        L.seq2 = L.seq + (K + 2);
-        L.seq3 = L.seq2 + (K + 2);
-        L.slot = L.seq3 + (K + 2);
-        L.T = reinterpret_cast<uint32_t *>(L.slot + (K + 2) + ((6 * L.ts + 4 * (K + 2)) & 1));
         uint64_t RF = 0;
-        { NX_T0 if (nx_walk(c, L, Kb, ALL, omega, WIT, RF)) REC = RF; NX_T1(11) }
+        { NX_T0 if (nx_walk<TWO>(c, L, Kb, ALL, omega, WIT, RF)) REC = RF; NX_T1(11) }
+    }
+    if (TWO) {
+        if (lane == 0) L.mail->cmd = 0;                                 // the helper may go
+        __syncthreads();
     }
 
     // ---- emit
@@ -1083,11 +1155,21 @@ hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t 
                              uint8_t *mask, int32_t *n_in, int32_t *flags)
 {
     if (B <= 0 || K <= 0) return hipSuccess;
-    size_t lds = ((3 * sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 16 * 8 + nx_lds_bytes(K);
+    size_t lds = ((3 * sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 32 * 8 + nx_lds_bytes(K);
     const size_t kw = (size_t)K * ((K + 63) / 64);
     lds += 8 * (kw < CQ_LDS_ADJ_WORDS ? kw : (size_t)CQ_LDS_ADJ_WORDS);
     if (node_limit <= 0) node_limit = 300000;
-    hipLaunchKernelGGL(max_clique_kernel, dim3(B), dim3(64), lds, st, adj, count, K, kstride, nws,
-                       (long long)node_limit, stack, mask, n_in, flags);
+    // Two wavefronts per problem (the walk's two set chains side by side) shorten a problem by a quarter and halve the problems a CU
+    // holds.  4096 copies of ONE problem, same box: K 139 1.21 -> 1.63 ms with two, a 240-feature pair 3.38 -> 2.94; the default
+    // bench step (4096 different problems: the long ones set the time) 81.3 -> 80.9 ms, one sequence without motion distortion
+    // 1 390 -> 1 526 scan-pairs/s.  ROAM_CLIQUE_TWO_WAVES=0 / 1 forces one / two (A/B runs).
+    static const int force = [] { const char *e = getenv("ROAM_CLIQUE_TWO_WAVES"); return e ? atoi(e) : -1; }();
+    const bool two = force >= 0 ? force != 0 : true;
+    if (two)
+        hipLaunchKernelGGL(max_clique_kernel<true>, dim3(B), dim3(128), lds, st, adj, count, K, kstride, nws,
+                           (long long)node_limit, stack, mask, n_in, flags);
+    else
+        hipLaunchKernelGGL(max_clique_kernel<false>, dim3(B), dim3(64), lds, st, adj, count, K, kstride, nws,
+                           (long long)node_limit, stack, mask, n_in, flags);
     return hipGetLastError();
 }
