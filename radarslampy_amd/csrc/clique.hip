@@ -159,11 +159,17 @@ extern "C" int roam_debug_clique_prof(unsigned long long *out, int reset)
 #define NX_L0
 #define NX_L1(k)
 #endif
+// what the wavefront of the search hands to its helper and gets back.  cmd 1, a descent of the walk: cand, adj[q] -> cand & adj[q]
+// (nx_walk); cmd 2, a degree pass of the solver: thr in deg, |P| in used, P in the first wavefront's sw -> the RM / UN / PE words of the
+// upper vertex groups in live / occ / row, their branching key in mask (cq_solve); cmd 0: leave
+struct NxMail { uint64_t live[64], occ[64], row[64]; int cmd, used, mask, ident, perfect, srctab, dsttab, deg; };
 struct CqCtx {
     const uint64_t *A;          // adjacency rows (LDS or global), stride `as` words
     int as, nw, nws, lane;
     int wv;                     // 0: the wavefront that runs the search, 1: its helper (the cand chain of the walk)
     uint64_t *sw;               // 16 words of LDS: the current set broadcast to all lanes
+    uint64_t *sw0;              // ... the first wavefront's
+    NxMail *mail;
     uint64_t *stk;              // global scratch: 2 * nws words per level
     short *lsize, *lv, *lstage; // per level: |R|, branching vertex, stage
     long long nodes, node_limit;
@@ -173,6 +179,27 @@ struct CqCtx {
 #endif
 };
 
+// the degree pass of cq_solve over the vertex groups [g0, g1): per group of 64 vertices the words RM (fewer than thr neighbours inside
+// P), UN (no conflict left), PE (one conflict) to lane g, and the lane's best branching key
+__device__ __forceinline__ void cq_degrees(const CqCtx &c, const uint64_t *sw, int g0, int g1, int thr, int cnt,
+                                           uint64_t &RM, uint64_t &UN, uint64_t &PE, int &key)
+{
+    const int lane = c.lane, nw = c.nw;
+    for (int g = g0; g < g1; g++) {
+        const int u = g * 64 + lane;
+        const bool in = (sw[g] >> lane) & 1ull;
+        int d = 0;
+        if (in)
+            for (int w = 0; w < nw; w++) d += __popcll(c.A[(int64_t)u * c.as + w] & sw[w]);
+        const uint64_t brm = __ballot(in && d < thr);
+        const uint64_t bun = __ballot(in && d == cnt - 1);
+        const uint64_t bpe = __ballot(in && d == cnt - 2);
+        if (lane == g) { RM = brm; UN = bun; PE = bpe; }
+        if (in) key = min(key, d * 2048 + (2047 - u));      // fewest neighbours = most conflicts; ties: largest index
+    }
+}
+
+template <bool TWO>
 __device__ __forceinline__ int cq_solve(CqCtx &c, uint64_t P0, int best, int target, uint64_t &REC)
 {
     const int lane = c.lane, nw = c.nw;
@@ -193,18 +220,23 @@ __device__ __forceinline__ int cq_solve(CqCtx &c, uint64_t P0, int best, int tar
                 const int thr = best - size;                            // an improving clique needs >= thr neighbours inside P
                 uint64_t RM = 0, UN = 0, PE = 0;
                 int key = 0x7fffffff;
-                for (int g = 0; g < nw; g++) {
-                    const int u = g * 64 + lane;
-                    const bool in = (c.sw[g] >> lane) & 1ull;
-                    int d = 0;
-                    if (in)
-                        for (int w = 0; w < nw; w++) d += __popcll(c.A[(int64_t)u * c.as + w] & c.sw[w]);
-                    const uint64_t brm = __ballot(in && d < thr);
-                    const uint64_t bun = __ballot(in && d == cnt - 1);
-                    const uint64_t bpe = __ballot(in && d == cnt - 2);
-                    if (lane == g) { RM = brm; UN = bun; PE = bpe; }
-                    if (in) key = min(key, d * 2048 + (2047 - u));      // fewest neighbours = most conflicts; ties: largest index
-                }
+#ifdef CQ_EXP_NOSPLIT
+                if (false) {
+#else
+                if (TWO && nw >= 2) {
+#endif
+                    // the upper half of the vertex groups on the helper wavefront (round 5: the pass is the solver's unit of time -
+                    // a dozen of them per search node - and the helper was idle outside the walk's descents)
+                    NxMail *mb = c.mail;
+                    const int gs = (nw + 1) >> 1;
+                    if (lane == 0) { mb->cmd = 2; mb->deg = thr; mb->used = cnt; }
+                    __syncthreads();
+                    cq_degrees(c, c.sw, 0, gs, thr, cnt, RM, UN, PE, key);
+                    __syncthreads();
+                    if (lane >= gs && lane < nw) { RM = mb->live[lane]; UN = mb->occ[lane]; PE = mb->row[lane]; }
+                    key = min(key, mb->mask);
+                } else
+                    cq_degrees(c, c.sw, 0, nw, thr, cnt, RM, UN, PE, key);
                 WSYNC();
                 if (__ballot(RM != 0)) { P &= ~RM; continue; }
                 if (__ballot(UN != 0)) { R |= UN; size += bs_count(UN); P &= ~UN; continue; }
@@ -317,8 +349,6 @@ struct NxSet {
     bool ident;
     bool perfect;       // explicit layout in which every key sits at its home slot key & mask (no key was ever displaced)
 };
-// what the wavefront of the search hands to its helper at a descent (cand, adj[q]) and gets back (cand & adj[q]): see nx_walk
-struct NxMail { uint64_t live[64], occ[64], row[64]; int cmd, used, mask, ident, perfect, srctab, dsttab, deg; };
 struct NxLds { uint16_t *tab[6], *seq, *seq2, *seq3, *slot; uint32_t *T; int ts; NxMail *mail; };
 
 __host__ __device__ inline int nx_table_slots(int K)
@@ -925,7 +955,19 @@ __device__ __forceinline__ void nx_helper(CqCtx &c, NxLds &L)
     NxMail *mb = L.mail;
     for (;;) {
         __syncthreads();
-        if (mb->cmd == 0) return;
+        const int cmd = mb->cmd;
+        if (cmd == 0) return;
+        if (cmd == 2) {
+            const int nw = c.nw, gs = (nw + 1) >> 1, thr = mb->deg, cnt = mb->used;
+            uint64_t RM = 0, UN = 0, PE = 0;
+            int key = 0x7fffffff;
+            cq_degrees(c, c.sw0, gs, nw, thr, cnt, RM, UN, PE, key);
+            if (lane >= gs && lane < nw) { mb->live[lane] = RM; mb->occ[lane] = UN; mb->row[lane] = PE; }
+            key = wave_min_i(key);
+            if (lane == 0) mb->mask = key;
+            __syncthreads();
+            continue;
+        }
         NxSet S, D;
         S.live = mb->live[lane]; S.occ = mb->occ[lane];
         S.used = mb->used; S.mask = mb->mask; S.ident = mb->ident != 0; S.perfect = mb->perfect != 0;
@@ -1013,7 +1055,7 @@ __device__ __forceinline__ bool nx_walk(CqCtx &c, NxLds &L, int Kb, uint64_t ALL
             c.nq++;
 #endif
             int got;
-            { NX_T0 got = cq_solve(c, Cq, need - 1, need, RQ); NX_T1(4) }
+            { NX_T0 got = cq_solve<TWO>(c, Cq, need - 1, need, RQ); NX_T1(4) }
             if (!c.complete) return false;
             if (got >= need) { ok = true; WIT = QB | RQ; }
         }
@@ -1087,13 +1129,14 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64
         c.A = adj_l; c.as = nw;
     } else { c.A = Ag; c.as = nws; }
     WSYNC();
-    c.nw = nw; c.nws = nws; c.lane = lane; c.wv = wv; c.sw = sw + 16 * wv;
+    c.nw = nw; c.nws = nws; c.lane = lane; c.wv = wv; c.sw = sw + 16 * wv; c.sw0 = sw;
     c.stk = stack_g + (int64_t)b * (kstride + 2) * 2 * nws;
     c.lsize = lsize; c.lv = lv; c.lstage = lstage;
     c.nodes = 0; c.node_limit = node_limit; c.complete = true;
     // The workgroup is two wavefronts.  The first runs the search; the second waits at the workgroup barrier for the cand chain of the
     // walk's descents (nx_helper) and leaves when the first says so.  They meet at those barriers ONLY - everything else in this file
     // synchronises a wavefront with itself (WSYNC).
+    { NxLds Lt; nx_lds_carve(Lt, nx_mem, K, 0); c.mail = Lt.mail; }
     if (TWO && wv == 1) {
         NxLds L1;
         nx_lds_carve(L1, nx_mem, K, 1);
@@ -1115,7 +1158,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64
     }
     // ---- phase 1: omega and one maximum clique (the witness)
     uint64_t WIT = 0;
-    const int omega = cq_solve(c, ALL, 0, 0x7fffffff, WIT);
+    const int omega = cq_solve<TWO>(c, ALL, 0, 0x7fffffff, WIT);
 #ifdef NX_EXP_STATS
     c.nq = 0; c.nodes1 = c.nodes;
 #endif
