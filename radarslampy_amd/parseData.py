@@ -88,6 +88,8 @@ def _decode_worker(shm_name, rec_bytes, tasks, done):
     shm = shared_memory.SharedMemory(name=shm_name)
     try:
         buf = np.ndarray((shm.size,), np.uint8, buffer=shm.buf)
+        buf[::4096] |= np.uint8(0)                               # map the whole ring into this process now (24 k soft page faults per
+        done.put((-1, -1, None, None, None))                     # worker otherwise spread over its first frames); then: ready
         while True:
             job = tasks.get()
             if job is None:
@@ -129,6 +131,12 @@ class RecordDecodePool:
                        for _ in range(self.workers)]
         for p in self._procs:
             p.start()
+        self._outstanding = self.workers                         # one "ready" message each: the ring is mapped, the imports are done
+        try:
+            self._drain()
+        except BaseException:
+            self.close()
+            raise
 
     def records(self, imgPaths):
         paths = list(imgPaths)

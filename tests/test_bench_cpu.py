@@ -212,12 +212,11 @@ def test_png_decode_process_pool_reports_dead_workers(tmp_path):
     Image.fromarray(np.zeros((4, 16), np.uint8)).save(p)
     code = (f"import sys; sys.path.insert(0, {ROOT!r})\n"
             "from radarslampy_amd.parseData import RecordDecodePool\n"
-            "pool = RecordDecodePool(workers=2, depth=2, rec_bytes=64)\n"
             "try:\n"
+            "    pool = RecordDecodePool(workers=2, depth=2, rec_bytes=64)\n"
             f"    list(pool.records([{str(p)!r}]))\n"
+            "    pool.close()\n"
             "except RuntimeError as e:\n"
-            "    print('RAISED', e)\n"
-            "finally:\n"
-            "    pool.close()\n")
+            "    print('RAISED', e)\n")
     out = subprocess.run([sys.executable, "-"], input=code, capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
     assert "RAISED RecordDecodePool: 2 of 2 decode processes died" in out.stdout, out.stdout + out.stderr[-2000:]
