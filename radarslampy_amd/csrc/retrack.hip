@@ -1503,8 +1503,9 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         const bool tr = trace && first / R < ntrace;
         hipEvent_t *tev = trace + 3 * (first / R);
         if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
-        if (W <= 2048 && a.fused) hipLaunchKernelGGL(rt_fused_kernel, dim3(P), dim3(FD_THREADS), FD_LDS_BYTES, st, a, first, 0);
-        else if (W <= 2048) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
+        if (W <= 2048 && a.fused && B - first >= RI_MIN_DETECTIONS) hipLaunchKernelGGL(rt_fused_kernel, dim3(P), dim3(FD_THREADS), FD_LDS_BYTES, st, a, first, 0);
+        else if (W <= 2048 && B - first >= RI_MIN_DETECTIONS)               // (fewer lanes left than a one-sweep chunk needs: it would return at once)
+            hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
         if ((e = hipGetLastError()) != hipSuccess) return e;              // (a refused launch - LDS attribute, grid - surfaces here, not after the chain)
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);

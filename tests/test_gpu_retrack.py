@@ -432,3 +432,32 @@ def test_one_sweep_integral_kernel_on_a_small_image():
         assert np.array_equal(eng.lane_features(b), want[b % 2]), b
     eng.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("nb,amp,sq,seed", [(40, 6, 3, 140), (90, 3, 2, 11)])
+def test_detection_of_the_full_candidate_class_matches_get_features(nb, amp, sq, seed):
+    """a detection with more than 1024 and at most 2048 determinant maxima takes rt_blobs_kernel<false> (global-memory pair lists, the
+    big set tables) instead of the LDS-resident class every other test reaches: 1 385 / 1 792 candidates on these two scans, within the
+    32 767 candidate pairs the bookkeeping holds - the features are the oracle's getFeatures (skimage pruning order, NumPy-1.22 sigma
+    order, SSC)"""
+    from radarslampy_amd import _ffi
+    from radarslampy_amd.engine import Engine
+    clip = 2025
+    rng = np.random.default_rng(seed)
+    pay = (rng.random((400, clip)) * amp).astype(np.uint8)
+    for _ in range(nb):
+        a, r = int(rng.integers(0, 400)), int(rng.integers(200, clip - 5))
+        pay[max(0, a - sq):a + sq, max(0, r - sq):r + sq] = rng.integers(150, 255)
+    ctx = _ffi.Context(0)
+    eng = Engine(1, 1, ctx=ctx, rows=400, stride=clip, payload_off=0, clip=clip, retrack_on_device=True)
+    eng.upload_scan(0, pay)
+    eng.init_lane_detect(0, 0, np.zeros(3))
+    got = eng.lane_features(0)
+    eng.step([0])                                                             # (the scratch of debug_detect is that of a step's detection)
+    n = eng.debug_detect(False, 1)[0]
+    assert 1024 < n[0] <= 2048, n
+    cart = oracle.convertPolarImageToCartesian(pay.astype(np.float32) / np.float32(255.))
+    want = oracle.append_dedupe(np.empty((0, 2)), _detect(cart))
+    assert len(want) > 100 and np.array_equal(got, want), (len(got), len(want))
+    eng.close()
+    ctx.close()

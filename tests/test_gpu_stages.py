@@ -3,6 +3,8 @@
 
 Bars: bit-exact for index / byte / integer work (peaks, warp+quantise, pyramid, KLT,
 adjacency, clique mask, SSC); 1e-4 m / 1e-5 rad for poses (Kabsch, motion-distortion LM)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -258,6 +260,34 @@ def test_reject_outliers_on_the_correspondence_sets_of_real_pairs(ctx, golden):
         mask, n_in, flags, adj = ctx.reject_outliers(p, n, oracle.DIST_THRESHOLD_PX, want_adj=True)
         size, omask, _ = oracle.max_clique_nx(adj)
         assert flags & 1 and n_in == size and np.array_equal(mask, omask), tag
+
+
+def test_reject_outliers_one_wavefront_variant_gives_the_same_masks(golden):
+    """max_clique_kernel runs two wavefronts per problem (solver + walk on the first, the cand chain of the walk's descents and half of
+    the solver's degree pass on the second); ROAM_CLIQUE_TWO_WAVES=0 (read at the first launch of a process) is the one-wavefront kernel
+    kept for A/B runs.  Both give the oracle's networkx-order clique on the sixteen real / bench-like sets and the reference's fixtures."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import oracle\n"
+        "from radarslampy_amd import _ffi\n"
+        "ctx = _ffi.Context(0)\n"
+        "G = os.path.join(sys.path[0], 'tests', 'golden')\n"
+        "g = np.load(os.path.join(G, 'clique_lone_sets.npz')); o = np.load(os.path.join(G, 'outliers.npz'))\n"
+        "sets = [(g[k[:-5] + '_prev'], g[k[:-5] + '_new']) for k in sorted(g.files) if k.endswith('_prev')]\n"
+        "sets += [(o[t + '_prev'], o[t + '_new']) for t in ('npz139', 'real95', 'u256')]\n"
+        "bad = 0\n"
+        "for p, n in sets:\n"
+        "    mask, n_in, flags, adj = ctx.reject_outliers(p, n, oracle.DIST_THRESHOLD_PX, want_adj=True)\n"
+        "    size, omask, _ = oracle.max_clique_nx(adj)\n"
+        "    bad += not (flags & 1 and n_in == size and np.array_equal(mask, omask))\n"
+        "print('CHECKED', len(sets), 'BAD', bad)\n")
+    for two in ("0", "1"):
+        env = dict(os.environ, ROAM_CLIQUE_TWO_WAVES=two)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert "CHECKED 19 BAD 0" in out.stdout, (two, out.stdout[-500:], out.stderr[-2000:])
 
 
 # ------------------------------------------------------------------ a10 Kabsch
