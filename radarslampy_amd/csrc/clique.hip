@@ -1100,10 +1100,11 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64
                                                         int nws, long long node_limit,
                                                         uint64_t *__restrict__ stack_g,
                                                         uint8_t *__restrict__ mask_out,
-                                                        int32_t *__restrict__ n_in, int32_t *__restrict__ flags)
+                                                        int32_t *__restrict__ n_in, int32_t *__restrict__ flags,
+                                                        const int32_t *__restrict__ order)
 {
     extern __shared__ __align__(16) unsigned char cq_smem[];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = order ? order[blockIdx.x] : blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Kb = count ? min(count[b], K) : K;
     uint8_t *mask = mask_out + (int64_t)b * kstride;
     if (Kb <= 0) {
@@ -1192,12 +1193,42 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64
 #endif
 }
 
+// order[0..B) = the problems by falling number of correspondences (a counting sort in one workgroup): the kernel's time is set by its
+// longest problems - the pairs right after a re-detection - and a workgroup that starts last should not be one of them
+__global__ __launch_bounds__(1024) void cq_order_kernel(const int32_t *__restrict__ count, int B, int K, int32_t *__restrict__ order, int shift)
+{
+    __shared__ int hist[1026];
+    const int t = threadIdx.x;
+    for (int i = t; i <= 1025; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) atomicAdd(&hist[1024 - min(min(count[i], K) >> shift, 1024)], 1);       // bucket 0 = the largest problems
+    __syncthreads();
+    if (t < 64) {                                                                                   // exclusive prefix over 1025 buckets: 17 per lane
+        int loc[17], sum = 0;
+        for (int k = 0; k < 17; k++) { const int i = t * 17 + k; loc[k] = i <= 1024 ? hist[i] : 0; sum += loc[k]; }
+        int inc = sum;
+        for (int d = 1; d < 64; d <<= 1) { const int n = __shfl_up(inc, d); if (t >= d) inc += n; }
+        int run = inc - sum;
+        for (int k = 0; k < 17; k++) { const int i = t * 17 + k; if (i <= 1024) hist[i] = run; run += loc[k]; }
+    }
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) order[atomicAdd(&hist[1024 - min(min(count[i], K) >> shift, 1024)], 1)] = i;
+}
+
+hipError_t launch_order_by_count(hipStream_t st, const int32_t *count, int B, int cmax, int32_t *order, int shift)
+{
+    hipLaunchKernelGGL(cq_order_kernel, dim3(1), dim3(1024), 0, st, count, B, cmax, order, shift);
+    return hipGetLastError();
+}
+
 // adj rows have stride nws words; stack scratch: B x (kstride+2) x 2 x nws words
 hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t *count, int K,
                              int kstride, int nws, int B, int64_t node_limit, uint64_t *stack,
-                             uint8_t *mask, int32_t *n_in, int32_t *flags)
+                             uint8_t *mask, int32_t *n_in, int32_t *flags, int32_t *order)
 {
     if (B <= 0 || K <= 0) return hipSuccess;
+    if (!count || B < 512 || getenv("ROAM_CLIQUE_NO_ORDER")) order = nullptr;
+    if (order) hipLaunchKernelGGL(cq_order_kernel, dim3(1), dim3(1024), 0, st, count, B, K, order, 0);
     size_t lds = ((3 * sizeof(short) * (size_t)(K + 2) + 15) & ~(size_t)15) + 32 * 8 + nx_lds_bytes(K);
     const size_t kw = (size_t)K * ((K + 63) / 64);
     lds += 8 * (kw < CQ_LDS_ADJ_WORDS ? kw : (size_t)CQ_LDS_ADJ_WORDS);
@@ -1210,9 +1241,9 @@ hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t 
     const bool two = force >= 0 ? force != 0 : true;
     if (two)
         hipLaunchKernelGGL(max_clique_kernel<true>, dim3(B), dim3(128), lds, st, adj, count, K, kstride, nws,
-                           (long long)node_limit, stack, mask, n_in, flags);
+                           (long long)node_limit, stack, mask, n_in, flags, (const int32_t *)order);
     else
         hipLaunchKernelGGL(max_clique_kernel<false>, dim3(B), dim3(64), lds, st, adj, count, K, kstride, nws,
-                           (long long)node_limit, stack, mask, n_in, flags);
+                           (long long)node_limit, stack, mask, n_in, flags, (const int32_t *)order);
     return hipGetLastError();
 }

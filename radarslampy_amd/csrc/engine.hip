@@ -58,6 +58,7 @@ struct Engine {
     float *good_old = nullptr, *good_new = nullptr;
     int32_t *good_idx = nullptr, *good_n = nullptr;
     uint64_t *adj = nullptr, *cq_stack = nullptr;
+    int32_t *cq_order = nullptr;     // B: the step's clique problems, largest first (launch_max_clique)
     uint8_t *cq_mask = nullptr;
     int32_t *cq_n = nullptr, *cq_flags = nullptr;
     double *kab_src = nullptr, *kab_tgt = nullptr, *kab_out = nullptr;
@@ -596,6 +597,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->good_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->adj, (size_t)B * KS * nw);
     ok = ok && dalloc(ctx, e, &e->cq_stack, (size_t)B * (KS + 2) * 2 * nw);
+    ok = ok && dalloc(ctx, e, &e->cq_order, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->cq_mask, (size_t)B * KS);
     ok = ok && dalloc(ctx, e, &e->cq_n, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->cq_flags, (size_t)B);
@@ -664,7 +666,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         ok = ok && dalloc(ctx, e, &r.order, D * (BP_MAX_PAIRS + 1)) && dalloc(ctx, e, &r.ovbits, D * ((BP_MAX_PAIRS + 31) / 32 + 1));
         ok = ok && dalloc(ctx, e, &r.bigtab, D * 2 * 131072);
         ok = ok && dalloc(ctx, e, &r.kp, D * BP_MAX_PTS * 3) && dalloc(ctx, e, &r.kp_n, D) && dalloc(ctx, e, &r.slot_flags, D);
-        ok = ok && dalloc(ctx, e, &r.ssc_work, D * 4 * BP_MAX_PTS) && dalloc(ctx, e, &r.sel, D * BP_MAX_PTS) && dalloc(ctx, e, &r.sel_n, D);
+        ok = ok && dalloc(ctx, e, &r.ssc_work, D * 4 * BP_MAX_PTS) && dalloc(ctx, e, &r.sel, D * BP_MAX_PTS) && dalloc(ctx, e, &r.sel_n, D) && dalloc(ctx, e, &r.blob_order_buf, D);
     }
     if (!ok) { roam_engine_destroy(ctx); return ROAM_E_HIP; }
     if (e->rt_on) {
@@ -1214,7 +1216,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     if (c.reject_outliers) {
         HIP_TRY(ctx, launch_consistency_graph(st, e->good_old, e->good_new, e->good_n, KM, KS, B, 0.5 / M_PER_PX, e->adj, nw));
         HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
-        HIP_TRY(ctx, launch_max_clique(st, e->adj, e->good_n, KM, KS, nw, B, c.clique_node_limit, e->cq_stack, e->cq_mask, e->cq_n, e->cq_flags));
+        HIP_TRY(ctx, launch_max_clique(st, e->adj, e->good_n, KM, KS, nw, B, c.clique_node_limit, e->cq_stack, e->cq_mask, e->cq_n, e->cq_flags, e->cq_order));
     } else {
         HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
         hipLaunchKernelGGL(fill_mask_kernel, dim3(B), dim3(256), 0, st, e->cq_mask, e->good_n, e->cq_n, e->cq_flags);

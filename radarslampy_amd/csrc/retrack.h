@@ -42,6 +42,9 @@ struct RtArgs {
     int32_t *kp_n, *slot_flags;
     int32_t *ssc_work;              // 4 x BP_MAX_PTS
     int32_t *sel, *sel_n;           // BP_MAX_PTS, 1
+    int32_t *blob_order_buf;        // one entry per lane: scratch of the order below
+    const int32_t *blob_order;      // the detections by falling number of candidates (set by launch_retrack for its bookkeeping kernels: the
+                                    // longest lists start first; null = slot order)
     // fused detection kernel (retrack_fused.inc: integral image + determinants + maxima in one kernel, chunks of >= RT_TWO_PASS_SLOTS detections)
     int fused;                      // 1: rt_fused_kernel serves those chunks, rt_integral_kernel / rt_det_strip_kernel return at once for them
     const uint32_t *fd_mapT;        // the sampling map transposed (W x W)

@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
 {
     typedef RtBlobCap<SMALL> CP;
     __shared__ RtBlobLds<SMALL> L;
-    const int ls = blockIdx.x, slot = first + ls;
+    const int ls = a.blob_order ? a.blob_order[blockIdx.x] : (int)blockIdx.x, slot = first + ls;
     if (slot >= *a.rt_n) return;
     const int lane = threadIdx.x;
     const int ncand = a.cand_n[ls];
@@ -1518,8 +1518,16 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if (tr && (e = hipEventRecord(tev[2], st)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
-    hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, a, 0);
-    hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, a, 0);
+    // the bookkeeping is one latency-bound wavefront per detection and its time grows with the candidate list: longest lists first
+    // (in the default step 2.1 -> ... ms for the kernel; the work is the same, the tail is not)
+    RtArgs ab = a;
+    ab.blob_order = nullptr;
+    if (B >= 512 && a.blob_order_buf) {
+        if ((e = launch_order_by_count(st, a.cand_n, B, BP_MAX_PTS, a.blob_order_buf, 1)) != hipSuccess) return e;
+        ab.blob_order = a.blob_order_buf;
+    }
+    hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, ab, 0);
+    hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, ab, 0);
     e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rt_append_kernel, dim3(B), dim3(256), 0, st, a, 0);

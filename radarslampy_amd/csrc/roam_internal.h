@@ -126,7 +126,11 @@ hipError_t launch_consistency_graph(hipStream_t st, const float *prev, const flo
 // max clique (lexicographically smallest maximum clique); stack scratch: B x (kstride+2) x 2 x nw words
 hipError_t launch_max_clique(hipStream_t st, const uint64_t *adj, const int32_t *count, int K,
                              int kstride, int nw, int B, int64_t node_limit, uint64_t *stack,
-                             uint8_t *mask, int32_t *n_in, int32_t *flags);
+                             uint8_t *mask, int32_t *n_in, int32_t *flags, int32_t *order = nullptr);      // order: B ints of scratch - the
+                                                                                                           // problems are then started largest first
+
+// order[0..B) = the indices 0..B-1 by falling min(count, cmax) >> shift (at most 1024 distinct keys): one workgroup, a counting sort
+hipError_t launch_order_by_count(hipStream_t st, const int32_t *count, int B, int cmax, int32_t *order, int shift);
 
 // Kabsch on f64 pairs: src/tgt B x nstride x 2; out: B x 6 doubles [R00 R01 R10 R11 hx hy]
 hipError_t launch_kabsch(hipStream_t st, const double *src, const double *tgt, const int32_t *count,
