@@ -418,16 +418,14 @@ BP_HDN void bp_aheapsort(const KEY *v, IDX *tosort, int n)
     }
 }
 
+// npy_aquicksort's loop on the segment [pl, pr] of tosort, entered with depth budget cdepth.  popped: the segment comes off the stack
+// (or is the whole array) - those are the segments the budget is checked on; a segment the loop simply goes on with is not
 template <typename KEY, typename IDX>
-BP_HDN void bp_aquicksort(const KEY *v, int num, IDX *tosort)
+BP_HDN void bp_aquicksort_range(const KEY *v, IDX *tosort, int pl, int pr, int cdepth, bool popped)
 {
-    for (int i = 0; i < num; i++) tosort[i] = (IDX)i;
-    if (num < 2) return;
-    int pl = 0, pr = num - 1, stack[128], sp = 0, depth[64], dp = 0, cdepth = 0;
-    for (int k = num; k > 1; k >>= 1) cdepth++;
-    cdepth *= 2;
+    int stack[128], sp = 0, depth[64], dp = 0;
     for (;;) {
-        if (cdepth < 0) bp_aheapsort(v, tosort + pl, pr - pl + 1);
+        if (popped && cdepth < 0) bp_aheapsort(v, tosort + pl, pr - pl + 1);
         else {
             while (pr - pl > 16) {
                 const int pm = pl + ((pr - pl) >> 1);
@@ -461,5 +459,16 @@ BP_HDN void bp_aquicksort(const KEY *v, int num, IDX *tosort)
         pr = stack[--sp];
         pl = stack[--sp];
         cdepth = depth[--dp];
+        popped = true;
     }
+}
+
+template <typename KEY, typename IDX>
+BP_HDN void bp_aquicksort(const KEY *v, int num, IDX *tosort)
+{
+    for (int i = 0; i < num; i++) tosort[i] = (IDX)i;
+    if (num < 2) return;
+    int cdepth = 0;
+    for (int k = num; k > 1; k >>= 1) cdepth++;
+    bp_aquicksort_range(v, tosort, 0, num - 1, 2 * cdepth, true);
 }

@@ -1068,6 +1068,96 @@ __device__ void rb_nth_element_wave(BpPt *pt, int first, int nth, int last, int 
     __syncthreads();
 }
 
+// np.argsort of NumPy 1.22 (npy_aquicksort) by the whole wavefront: tosort = the permutation bp_aquicksort leaves, element for element.
+// Quicksort's segments are disjoint, so the order they are processed in does not matter - only each segment's depth budget does (a child's
+// is its parent's minus one; the budget is checked on segments that come off the stack, i.e. the LARGER child of a partition and the whole
+// array).  Segments of more than QS_WAVE_MIN elements are partitioned by all lanes (median of three on uniform values, then the Hoare
+// loop as the two ordered lists of stop positions: L = positions in (pl, pr) whose key is not below the pivot, R = positions in [pl, pr - 1)
+// whose key is not above it, read from the right; the loop swaps L[i] with R[i] while L[i] < R[i] and ends at min(L[k], R[k - 1]) -
+// tests/test_parallel_partition_model.py); the smaller ones are sorted one lane per segment, all at once, by the sequential code.
+// 530 two-valued sigmas on one lane were ~100 us of a lone detection's bookkeeping.  work: 3 x 256 ints, Lp / Rp: num uint16 each.
+#define QS_WAVE_MIN 64
+__device__ void rb_aquicksort_wave(const uint8_t *v, int num, int16_t *ts, int lane, int *work, uint16_t *Lp, uint16_t *Rp)
+{
+    for (int i = lane; i < num; i += 64) ts[i] = (int16_t)i;
+    __syncthreads();
+    if (num < 2) return;
+    int cdepth = 0;
+    for (int k = num; k > 1; k >>= 1) cdepth++;
+    cdepth *= 2;
+    // work[3k..3k+2] = (pl, pr, cdepth << 1 | popped); big segments are taken from the top, small ones collected from the bottom of the
+    // second half (at most num / 17 + 1 leaves of 17+ elements and as many pending segments: 256 entries hold 2048 keys)
+    int sp = 0, nsmall = 0;
+    int *small = work + 3 * 128;
+    int pl = 0, pr = num - 1, cd = cdepth;
+    bool popped = true;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (;;) {
+        if (pr - pl <= QS_WAVE_MIN || nsmall + sp + 2 >= 128) {           // (the second condition cannot arise; a full list would only cost time)
+            if (lane == 0) { small[3 * nsmall] = pl; small[3 * nsmall + 1] = pr; small[3 * nsmall + 2] = cd * 2 + (popped ? 1 : 0); }
+            nsmall++;
+        } else if (popped && cd < 0) {
+            if (lane == 0) bp_aheapsort(v, ts + pl, pr - pl + 1);
+            __syncthreads();
+        } else {
+            const int pm = pl + ((pr - pl) >> 1);
+            int a = ts[pl], b = ts[pm], c = ts[pr];                        // (uniform reads)
+            if (v[b] < v[a]) { const int t = a; a = b; b = t; }
+            if (v[c] < v[b]) { const int t = c; c = b; b = t; }
+            if (v[b] < v[a]) { const int t = a; a = b; b = t; }
+            const int vp = v[b], old = ts[pr - 1];
+            __syncthreads();
+            if (lane == 0) { ts[pl] = (int16_t)a; ts[pr] = (int16_t)c; ts[pm] = (int16_t)old; ts[pr - 1] = (int16_t)b; }
+            if (pm == pr - 1 && lane == 0) ts[pm] = (int16_t)b;          // (never: pr - pl > 64)
+            __syncthreads();
+            int nL = 0, nR = 0;
+            for (int c0 = pl; c0 < pr; c0 += 64) {
+                const int pos = c0 + lane;
+                const bool in = pos < pr;
+                const int k = in ? (int)v[ts[pos]] : 0;
+                const bool ge = in && pos > pl && !(k < vp), le = in && pos < pr - 1 && !(vp < k);
+                const uint64_t bl = __ballot(ge), br = __ballot(le);
+                if (ge) Lp[nL + __popcll(bl & below)] = (uint16_t)pos;
+                if (le) Rp[nR + __popcll(br & below)] = (uint16_t)pos;
+                nL += __popcll(bl); nR += __popcll(br);
+            }
+            __syncthreads();
+            const int nm = min(nL, nR);
+            int kk = 0;
+            for (int i0 = 0; i0 < nm; i0 += 64) {
+                const int i = i0 + lane;
+                const uint64_t bal = __ballot(i < nm && Lp[i] < Rp[nR - 1 - i]);
+                kk += __popcll(bal);
+                if (__popcll(bal) < min(64, nm - i0)) break;
+            }
+            for (int i = lane; i < kk; i += 64) { const int x = Lp[i], y = Rp[nR - 1 - i]; const int16_t t = ts[x]; ts[x] = ts[y]; ts[y] = t; }
+            const int pi = kk == 0 ? (int)Lp[0] : min((int)Lp[kk], (int)Rp[nR - kk]);
+            __syncthreads();
+            if (lane == 0) { const int16_t t = ts[pi]; ts[pi] = ts[pr - 1]; ts[pr - 1] = t; }
+            __syncthreads();
+            cd--;
+            int ql, qr;                                                   // the larger part goes to the stack, the smaller one is next
+            if (pi - pl < pr - pi) { ql = pi + 1; qr = pr; pr = pi - 1; }
+            else { ql = pl; qr = pi - 1; pl = pi + 1; }
+            if (lane == 0) { work[3 * sp] = ql; work[3 * sp + 1] = qr; work[3 * sp + 2] = cd; }
+            sp++;
+            popped = false;
+            continue;
+        }
+        if (sp == 0) break;
+        sp--;
+        __syncthreads();
+        pl = work[3 * sp]; pr = work[3 * sp + 1]; cd = work[3 * sp + 2];
+        popped = true;
+    }
+    __syncthreads();
+    for (int k = lane; k < nsmall; k += 64) {
+        const int a = small[3 * k], b = small[3 * k + 1], c = small[3 * k + 2];
+        bp_aquicksort_range(v, ts, a, b, c >> 1, (c & 1) != 0);
+    }
+    __syncthreads();
+}
+
 // bp_build_node by the whole wavefront (uniform start / end); the same return value and node fields
 __device__ int rb_build_node_wave(BpPt *pt, int start, int end, BpNode &nd, int lane, uint16_t *Lp, uint16_t *Rp)
 {
@@ -1136,9 +1226,24 @@ __device__ int rb_build_node_wave(BpPt *pt, int start, int end, BpNode &nd, int 
     return p;
 }
 
+#ifdef RB_EXP_PROF
+__device__ unsigned long long rb_prof[16];
+extern "C" int roam_debug_blob_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rb_prof), sizeof(rb_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rb_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define RB_P(k) { const unsigned long long tn_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) rbp_[k] += tn_ - rbt_; rbt_ = tn_; }
+#else
+#define RB_P(k)
+#endif
 template <bool SMALL>
 __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
 {
+#ifdef RB_EXP_PROF
+    unsigned long long rbp_[12] = {0}, rbt_ = __builtin_readcyclecounter();
+#endif
     typedef RtBlobCap<SMALL> CP;
     __shared__ RtBlobLds<SMALL> L;
     const int ls = a.blob_order ? a.blob_order[blockIdx.x] : (int)blockIdx.x, slot = first + ls;
@@ -1181,6 +1286,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         }
     }
     __syncthreads();
+    RB_P(0)
     // 2. cKDTree, level by level: every node of a level is built by its own lane (bounds, libstdc++ nth_element, scipy's
     // partition passes - sequential per node, but a level's nodes work on disjoint index ranges), so the critical path is the
     // largest node of every level (~2 n element visits) instead of all of them (~n log n: the build on lane 0 was 1.6 of this
@@ -1238,6 +1344,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     }
     for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)(pt[i].v >> 32);          // cKDTree.indices
     __syncthreads();
+    RB_P(1)
     // dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
     BpTask *tasks = a.tasks + (int64_t)ls * BP_MAX_TASKS;
     if (lane == 0) {
@@ -1255,6 +1362,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     __syncthreads();
     const int nt = L.vals[0];
     flags = L.vals[1];
+    RB_P(2)
     // 3. the pairs of the blocks in emission order (i-major, j ascending), 64 candidates per ballot
     uint32_t *pairs = a.pairs + (int64_t)ls * (BP_MAX_PAIRS + 1);
     const double ub = L.tr.ub;
@@ -1287,6 +1395,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     }
     if (np > BP_MAX_PAIRS) { flags |= RT_F_PAIR_OVERFLOW; np = BP_MAX_PAIRS; }
     __syncthreads();
+    RB_P(3)
     // 4. which pairs overlap by more than 0.5 (original sigmas: a pair with a pruned member never changes anything)
     if (SMALL && np > CP::LDS_PAIRS) {                                       // more pairs than the small set tables order: the full kernel's
         if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
@@ -1307,6 +1416,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         if (lane == 0) { ovb[w0 >> 5] = (uint32_t)bal; ovb[(w0 >> 5) + 1] = (uint32_t)(bal >> 32); }
     }
     __syncthreads();
+    RB_P(4)
     // 5. Python-set iteration order of the pairs + the sequential pruning pass, then 6. NumPy-1.22 argsort of the sigmas
     uint16_t *order = a.order + (int64_t)ls * (BP_MAX_PAIRS + 1);
     if (lane == 0) {
@@ -1321,6 +1431,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         L.vals[2] = m < 0 ? 0 : m;
     }
     __syncthreads();
+    RB_P(5)
     // the overlapping pairs in set order, gathered by the whole wave (the hash tables are free again: 4096 pairs fit in tabB);
     // the sequential pass then walks LDS only - one lane chasing order[k] -> pairs[q] through global memory was 2/3 of this kernel
     const int m = L.vals[2];
@@ -1359,20 +1470,37 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
                 if (L.lay[i] > L.lay[j]) L.lay[j] = 0; else L.lay[i] = 0;
             }
         }
-        // survivors in response order (reuse xy / lay in place), sorted by sigma with NumPy 1.22's tie order
-        int mb = 0;
-        for (int i = 0; i < n; i++)
-            if (L.lay[i]) { L.xy[2 * mb] = L.xy[2 * i]; L.xy[2 * mb + 1] = L.xy[2 * i + 1]; L.lay[mb] = L.lay[i]; mb++; }
-        bp_aquicksort(L.lay, mb, L.idx);
-        L.vals[0] = mb; L.vals[1] = flags;
+        L.vals[1] = flags;
     }
     __syncthreads();
-    const int mb = L.vals[0];
+    RB_P(6)
+    // survivors in response order (reuse xy / lay in place: a chunk of 64 is read before anything of it is overwritten, and what it writes
+    // lies at or below its own positions), then sorted by sigma with NumPy 1.22's tie order.  (On lane 0 this loop was ~40 us of a lone
+    // detection: 530 dependent LDS round trips.)
+    int mb = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const int ly = i < n ? (int)L.lay[i] : 0;
+        const int16_t x = i < n ? L.xy[2 * i] : (int16_t)0, y = i < n ? L.xy[2 * i + 1] : (int16_t)0;
+        const uint64_t bal = __ballot(ly != 0);
+        __syncthreads();
+        if (ly) { const int o = mb + __popcll(bal & ((1ull << lane) - 1ull)); L.xy[2 * o] = x; L.xy[2 * o + 1] = y; L.lay[o] = (uint8_t)ly; }
+        mb += __popcll(bal);
+        __syncthreads();
+    }
+    RB_P(7)
+    rb_aquicksort_wave(L.lay, mb, L.idx, lane, L.st, reinterpret_cast<uint16_t *>(L.pl), reinterpret_cast<uint16_t *>(L.pl) + CP::NP);
+    RB_P(8)
     for (int q = lane; q < mb; q += 64) {
         const int i = L.idx[q];
         kp[3 * q] = (double)L.xy[2 * i]; kp[3 * q + 1] = (double)L.xy[2 * i + 1]; kp[3 * q + 2] = L.lay[i] == 2 ? a.sigma2 : a.sigma1;
     }
     if (lane == 0) { a.kp_n[ls] = mb; a.slot_flags[ls] = L.vals[1]; }
+    RB_P(9)
+#ifdef RB_EXP_PROF
+    if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&rb_prof[k], rbp_[k]);
+    if (lane == 0) { atomicAdd(&rb_prof[12], 1ull); atomicAdd(&rb_prof[13], (unsigned long long)n); atomicAdd(&rb_prof[14], (unsigned long long)mb); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ K7: append + keyframe refresh

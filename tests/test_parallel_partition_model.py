@@ -126,3 +126,64 @@ def test_parallel_partitions_equal_the_sequential_algorithms():
         assert _scipy_sequential(A, s, n, split, key) == _scipy_parallel(A, s, n, split, key), (n, span)
         done += 1
     assert done > 3900
+
+
+# ---------------------------------------------------------------------------------------------- npy_aquicksort, segment by segment
+def aquicksort_par(v):
+    """segments in any order; partition by the list rule; insertion sorts at the end"""
+    n = len(v); ts = list(range(n))
+    if n < 2: return ts
+    cdepth = 0; k = n
+    while k > 1: k >>= 1; cdepth += 1
+    cdepth *= 2
+    work = [(0, n - 1, cdepth, True)]; leaves = []
+    while work:
+        pl, pr, cd, pushed = work.pop(rng_order.randrange(len(work)))       # any order
+        if pushed and cd < 0: raise RuntimeError("heapsort")
+        if pr - pl <= 16: leaves.append((pl, pr)); continue
+        pm = pl + ((pr - pl) >> 1)
+        if v[ts[pm]] < v[ts[pl]]: ts[pm], ts[pl] = ts[pl], ts[pm]
+        if v[ts[pr]] < v[ts[pm]]: ts[pr], ts[pm] = ts[pm], ts[pr]
+        if v[ts[pm]] < v[ts[pl]]: ts[pm], ts[pl] = ts[pl], ts[pm]
+        vp = v[ts[pm]]
+        ts[pm], ts[pr - 1] = ts[pr - 1], ts[pm]
+        L = [p for p in range(pl + 1, pr) if not (v[ts[p]] < vp)]            # ascending; ends with pr - 1
+        R = [p for p in range(pr - 2, pl - 1, -1) if not (vp < v[ts[p]])]     # descending; ends with pl
+        kk = 0
+        while kk < min(len(L), len(R)) and L[kk] < R[kk]: kk += 1
+        for i in range(kk): ts[L[i]], ts[R[i]] = ts[R[i]], ts[L[i]]
+        pi = L[0] if kk == 0 else min(L[kk], R[kk - 1])
+        ts[pi], ts[pr - 1] = ts[pr - 1], ts[pi]
+        cd -= 1
+        if pi - pl < pr - pi:
+            work.append((pi + 1, pr, cd, True)); work.append((pl, pi - 1, cd, False))
+        else:
+            work.append((pl, pi - 1, cd, True)); work.append((pi + 1, pr, cd, False))
+    for pl, pr in leaves:
+        for i in range(pl + 1, pr + 1):
+            vi = ts[i]; j = i
+            while j > pl and v[vi] < v[ts[j - 1]]: ts[j] = ts[j - 1]; j -= 1
+            ts[j] = vi
+    return ts
+
+
+
+def test_aquicksort_segments_in_any_order_with_list_rule_partitions():
+    """csrc/retrack.hip rb_aquicksort_wave: NumPy 1.22's argsort (npy_aquicksort) with its segments processed in ANY order - each with
+    the depth budget of its parent minus one - and every Hoare loop replaced by the two ordered lists of stop positions, against the
+    oracle's restatement of the sequential algorithm (itself pinned against NumPy 1.22.3 outputs): two-valued keys (the detector's
+    sigmas), all-equal keys, few and many distinct keys, 1 to 1 500 elements"""
+    import numpy as np
+    import oracle
+    global rng_order
+    rng_order = random.Random(9)
+    rng = random.Random(3)
+    for t in range(1200):
+        n = rng.choice([1, 2, 17, 18, 40, 100, 257, 530, 1024, 1500])
+        nv = rng.choice([1, 2, 2, 2, 3, 10, 1000])
+        v = [float(rng.randrange(nv)) for _ in range(n)]
+        if nv == 2:
+            f = rng.random()
+            v = [1.0 if rng.random() < f else 2.0 for _ in range(n)]
+        want = oracle.argsort_numpy122(np.array(v)).tolist()
+        assert aquicksort_par(v) == want, (t, n, nv)
