@@ -978,8 +978,8 @@ template <bool SMALL> struct RtBlobLds {
     uint8_t lay[CP::NP];              // layer (1 | 2) in response order; 0 = pruned
     BpNode nodes[CP::NNODE];
     int st[3 * 256];
-    int bstack[3 * 64];
-    BpTracker tr;
+    int16_t nbox[CP::NNODE][4];       // query_pairs' tracker box of every node: the root's bounds cut by the split planes on the way down
+                                      // ({min0, max0, min1, max1}; filled as the nodes are built)
     uint16_t tabA[CP::CAPA];
     alignas(8) uint16_t tabB[CP::CAPB];   // hash table of the set order; before that the packed points of the tree build (NP x 8 B)
     uint32_t ovbits[(CP::LDS_PAIRS + 31) / 32 + 1];
@@ -1296,6 +1296,18 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
         pt[i].v = (uint64_t)(uint16_t)L.xy[2 * i] | ((uint64_t)(uint16_t)L.xy[2 * i + 1] << 16) | ((uint64_t)i << 32);
     int nn = 0;
     if (n > 0) {
+        {
+            int mn0 = 32767, mx0 = -32768, mn1 = 32767, mx1 = -32768;
+            for (int i = lane; i < n; i += 64) {
+                const int v0 = L.xy[2 * i], v1 = L.xy[2 * i + 1];
+                mn0 = min(mn0, v0); mx0 = max(mx0, v0); mn1 = min(mn1, v1); mx1 = max(mx1, v1);
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                mn0 = min(mn0, __shfl_xor(mn0, d)); mx0 = max(mx0, __shfl_xor(mx0, d));
+                mn1 = min(mn1, __shfl_xor(mn1, d)); mx1 = max(mx1, __shfl_xor(mx1, d));
+            }
+            if (lane == 0) { L.nbox[0][0] = (int16_t)mn0; L.nbox[0][1] = (int16_t)mx0; L.nbox[0][2] = (int16_t)mn1; L.nbox[0][3] = (int16_t)mx1; }
+        }
         if (lane == 0) { L.nodes[0].start = 0; L.nodes[0].end = (int16_t)n; }
         nn = 1;
         __syncthreads();
@@ -1327,6 +1339,9 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
                         nd.less = (int16_t)c0; nd.greater = (int16_t)(c0 + 1);
                         L.nodes[c0].start = (int16_t)start; L.nodes[c0].end = (int16_t)p;
                         L.nodes[c0 + 1].start = (int16_t)p; L.nodes[c0 + 1].end = (int16_t)end;
+                        for (int k = 0; k < 4; k++) L.nbox[c0][k] = L.nbox[c0 + 1][k] = L.nbox[me][k];
+                        L.nbox[c0][2 * nd.split_dim + 1] = (int16_t)nd.split;      // less: max = split
+                        L.nbox[c0 + 1][2 * nd.split_dim] = (int16_t)nd.split;      // greater: min = split
                     }
                     L.nodes[me] = nd;
                 }
@@ -1345,27 +1360,103 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)(pt[i].v >> 32);          // cKDTree.indices
     __syncthreads();
     RB_P(1)
-    // dual-tree traversal -> ordered leaf x leaf blocks (sequential: lane 0)
+    // dual-tree traversal -> ordered leaf x leaf blocks.  query_pairs recurses over node pairs with a distance tracker it pushes and pops; on
+    // integer pixel coordinates every quantity of that tracker is an exact integer, so its state at a node pair is a function of the two
+    // nodes' boxes alone (nbox) and the recursion needs no stack: the pairs are expanded LEVEL BY LEVEL, every item replaced in place by its
+    // children in the recursion's order (a finished leaf x leaf block is its own child), so that the list stays in emission order throughout.
+    // One lane per item, ballots for the offsets; two lists of BP_MAX_TASKS packed items ping-pong in the detection's pair scratch.  (On lane 0
+    // the recursion was 45 % of this kernel: ~230 us of a lone detection.)  item = a | b << 10 | m << 20; m: 0 check, 1 no check, 2 / 3 block
+    // with / without the distance test
     BpTask *tasks = a.tasks + (int64_t)ls * BP_MAX_TASKS;
-    if (lane == 0) {
-        int nt = 0;
-        if (nn < 0) flags |= RT_F_TREE_OVERFLOW;
-        else if (n > 1) {
-            const double smax = a.sigma2;                    // _prune_blobs: distance = 2 * max sigma * sqrt(2)
-            bool any2 = false;
-            for (int i = 0; i < n; i++) any2 = any2 || L.lay[i] == 2;
-            nt = bp_tasks(L.xy, n, L.nodes, 2 * (any2 ? smax : a.sigma1) * 1.4142135623730951, tasks, BP_MAX_TASKS, L.st, 256, L.tr);
-            if (nt < 0) { flags |= RT_F_TREE_OVERFLOW; nt = 0; }
+    int nt = 0;
+    double ub = 0;
+    {
+        bool any2l = false;
+        for (int i = lane; i < n; i += 64) any2l = any2l || L.lay[i] == 2;
+        const bool any2 = __ballot(any2l) != 0;
+        const double r = 2 * (any2 ? a.sigma2 : a.sigma1) * 1.4142135623730951;      // _prune_blobs: distance = 2 * max sigma * sqrt(2)
+        ub = r * r;
+    }
+    if (nn < 0) flags |= RT_F_TREE_OVERFLOW;
+    else if (n > 1) {
+        const int t_gt = (int)floor(ub), t_lt = (int)ceil(ub);              // integer d: d > ub <=> d > t_gt, d < ub <=> d < t_lt
+        uint32_t *fa = a.pairs + (int64_t)ls * (BP_MAX_PAIRS + 1), *fb = fa + BP_MAX_TASKS;
+        if (lane == 0) fa[0] = 0u;                                          // (root, root, check)
+        int F = 1;
+        bool over = false;
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (;;) {
+            __syncthreads();
+            int total = 0;
+            bool open = false;
+            for (int c0 = 0; c0 < F; c0 += 64) {
+                const bool act = c0 + lane < F;
+                const uint32_t it = act ? fa[c0 + lane] : 0u;
+                const int na = it & 1023, nb = (it >> 10) & 1023;
+                int m = act ? (int)(it >> 20) : 2;
+                uint32_t ch[4];
+                int cnt = 0;
+                if (act && m >= 2) { ch[0] = it; cnt = 1; }
+                else if (act) {
+                    const BpNode n1 = L.nodes[na], n2 = L.nodes[nb];
+                    const bool l1 = n1.split_dim == -1, l2 = n2.split_dim == -1;
+                    bool pruned = false;
+                    if (m == 0) {
+                        int mind = 0, maxd = 0;
+                        for (int k = 0; k < 2; k++) {
+                            const int a0 = L.nbox[na][2 * k], a1 = L.nbox[na][2 * k + 1], b0 = L.nbox[nb][2 * k], b1 = L.nbox[nb][2 * k + 1];
+                            const int lo = max(max(a0 - b1, b0 - a1), 0), hi = max(a1 - b0, b1 - a0);
+                            mind += lo * lo; maxd += hi * hi;
+                        }
+                        if (mind > t_gt) pruned = true;
+                        else if (maxd < t_lt) m = 1;
+                    }
+                    const uint32_t mm = (uint32_t)m << 20;
+                    if (pruned) cnt = 0;
+                    else if (l1 && l2) { ch[0] = (uint32_t)na | ((uint32_t)nb << 10) | ((m == 0 ? 2u : 3u) << 20); cnt = 1; }
+                    else if (m == 1) {
+                        if (l1) { ch[0] = na | ((uint32_t)n2.less << 10) | mm; ch[1] = na | ((uint32_t)n2.greater << 10) | mm; cnt = 2; }
+                        else if (na == nb) {
+                            ch[0] = n1.less | ((uint32_t)n2.less << 10) | mm; ch[1] = n1.less | ((uint32_t)n2.greater << 10) | mm;
+                            ch[2] = n1.greater | ((uint32_t)n2.greater << 10) | mm; cnt = 3;
+                        } else { ch[0] = n1.less | ((uint32_t)nb << 10) | mm; ch[1] = n1.greater | ((uint32_t)nb << 10) | mm; cnt = 2; }
+                    } else {
+                        if (l1) { ch[0] = na | ((uint32_t)n2.less << 10); ch[1] = na | ((uint32_t)n2.greater << 10); cnt = 2; }
+                        else if (l2) { ch[0] = n1.less | ((uint32_t)nb << 10); ch[1] = n1.greater | ((uint32_t)nb << 10); cnt = 2; }
+                        else {
+                            ch[0] = n1.less | ((uint32_t)n2.less << 10); ch[1] = n1.less | ((uint32_t)n2.greater << 10); cnt = 2;
+                            if (na != nb) ch[cnt++] = n1.greater | ((uint32_t)n2.less << 10);
+                            ch[cnt++] = n1.greater | ((uint32_t)n2.greater << 10);
+                        }
+                    }
+                }
+                const uint64_t b1 = __ballot(cnt >= 1), b2 = __ballot(cnt >= 2), b3 = __ballot(cnt >= 3), b4 = __ballot(cnt >= 4);
+                const int off = total + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below) + __popcll(b4 & below);
+                const int sum = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4);
+                if (total + sum > BP_MAX_TASKS) { over = true; break; }     // (uniform)
+                for (int j = 0; j < cnt; j++) fb[off + j] = ch[j];
+                open = open || (cnt > 0 && (ch[0] >> 20) < 2u);             // (a node's children are all of one kind)
+                total += sum;
+            }
+            if (over) break;
+            uint32_t *t = fa; fa = fb; fb = t;
+            F = total;
+            if (!__ballot(open)) break;
         }
-        L.vals[0] = nt; L.vals[1] = flags;
+        __syncthreads();
+        if (over) flags |= RT_F_TREE_OVERFLOW;
+        else {
+            nt = F;
+            for (int i = lane; i < nt; i += 64) {
+                const uint32_t it = fa[i];
+                tasks[i].a = (int16_t)(it & 1023); tasks[i].b = (int16_t)((it >> 10) & 1023); tasks[i].mode = (int32_t)(it >> 20) - 2;
+            }
+        }
     }
     __syncthreads();
-    const int nt = L.vals[0];
-    flags = L.vals[1];
     RB_P(2)
     // 3. the pairs of the blocks in emission order (i-major, j ascending), 64 candidates per ballot
     uint32_t *pairs = a.pairs + (int64_t)ls * (BP_MAX_PAIRS + 1);
-    const double ub = L.tr.ub;
     int np = 0;
     for (int t = 0; t < nt; t++) {
         const BpTask tk = tasks[t];
