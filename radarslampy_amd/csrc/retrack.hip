@@ -1226,6 +1226,86 @@ __device__ int rb_build_node_wave(BpPt *pt, int start, int end, BpNode &nd, int 
     return p;
 }
 
+// bp_pyset_order by the whole wavefront: the same tables, slot for slot.  What is sequential in a CPython set is the INSERTION (the slot a
+// key takes depends on the slots taken before it); everything around it is not - the tuple hashes (two 64-bit multiplications each: 64
+// keys at a time, one per lane), clearing a new table, listing the old table's keys in slot order at a resize, reading the final table
+// out.  The insertions themselves run on wave-uniform values (hash and key by v_readlane, uniform table reads), chunk by chunk up to
+// the next resize.  order doubles as the scratch list of a resize (it is the output: free until the end).
+template <typename ORD>
+__device__ int rb_pyset_order_wave(const uint32_t *pairs, int np, uint16_t *tabA, int capA, uint16_t *tabB, int capB, ORD *order, int lane)
+{
+    uint16_t *tab = tabA, *other = tabB;
+    int cap_other = capB, cap_cur = capA;
+    uint32_t mask = 7;
+    if (lane < 8) tab[lane] = 0;
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+    int fill = 0;
+    // src = nullptr: the pairs p0 .. p0 + cnt - 1 themselves; else the keys listed in src[0 .. cnt)
+    auto insert_chunk = [&](uint16_t *t, uint32_t msk, const ORD *src, int p0, int cnt) {
+        const int key1 = lane < cnt ? (src ? (int)src[p0 + lane] : p0 + lane + 1) : 0;
+        const uint64_t h = key1 ? bp_tuple_hash(pairs[key1 - 1]) : 0ull;
+        for (int j = 0; j < cnt; j++) {
+            const uint64_t hj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(h >> 32), j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(h & 0xffffffffull), j);
+            const int kj = __builtin_amdgcn_readlane(key1, j);
+            uint64_t perturb = hj;
+            uint32_t i = (uint32_t)hj & msk;
+            for (;;) {
+                const int probes = (i + 9 <= msk) ? 9 : 0;
+                int e = -1;
+                for (int q = 0; q <= probes; q++) if (t[i + q] == 0) { e = (int)i + q; break; }
+                if (e >= 0) { if (lane == 0) t[e] = (uint16_t)kj; break; }
+                perturb >>= 5;
+                i = (uint32_t)(((uint64_t)i * 5 + 1 + perturb) & msk);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // (the next key reads what this one wrote)
+        }
+    };
+    for (int p = 0; p < np;) {
+        // insertions until the next resize: the smallest k with (fill + k) * 5 >= mask * 3
+        int room = (int)(((uint64_t)mask * 3 + 4) / 5) - fill;
+        if (room < 1) room = 1;
+        const int cnt = min(min(64, np - p), room);
+        insert_chunk(tab, mask, (const ORD *)nullptr, p, cnt);
+        p += cnt; fill += cnt;
+        __syncthreads();
+        if ((uint64_t)fill * 5 >= (uint64_t)mask * 3) {
+            const int minused = fill > 50000 ? fill * 2 : fill * 4;
+            uint32_t newsize = 8;
+            while ((int)newsize <= minused) newsize <<= 1;
+            if ((int)newsize > cap_other) return -1;
+            for (uint32_t k = lane; k < newsize; k += 64) other[k] = 0;
+            int m = 0;
+            for (uint32_t k0 = 0; k0 <= mask; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const int key = k <= mask ? (int)tab[k] : 0;
+                const uint64_t bal = __ballot(key != 0);
+                if (key) order[m + __popcll(bal & below)] = (ORD)key;
+                m += __popcll(bal);
+            }
+            __syncthreads();
+            for (int q = 0; q < m; q += 64) insert_chunk(other, newsize - 1, order, q, min(64, m - q));
+            __syncthreads();
+            uint16_t *t = tab; tab = other; other = t;
+            const int c = cap_cur; cap_cur = cap_other; cap_other = c;
+            mask = newsize - 1;
+        }
+    }
+    __syncthreads();
+    int m = 0;
+    for (uint32_t k0 = 0; k0 <= mask; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        const int key = k <= mask ? (int)tab[k] : 0;
+        const uint64_t bal = __ballot(key != 0);
+        // (order may still hold a resize's list below m: every entry is rewritten before it is read again, and what is written at
+        // position m + rank comes from slot k >= its old position - the final scan only ever overwrites entries it has passed)
+        if (key) order[m + __popcll(bal & below)] = (ORD)(key - 1);
+        m += __popcll(bal);
+    }
+    __syncthreads();
+    return m;
+}
+
 #ifdef RB_EXP_PROF
 __device__ unsigned long long rb_prof[16];
 extern "C" int roam_debug_blob_prof(unsigned long long *out, int reset)
@@ -1510,16 +1590,16 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     RB_P(4)
     // 5. Python-set iteration order of the pairs + the sequential pruning pass, then 6. NumPy-1.22 argsort of the sigmas
     uint16_t *order = a.order + (int64_t)ls * (BP_MAX_PAIRS + 1);
-    if (lane == 0) {
+    {
         int m;
-        if (lds_pl) m = bp_pyset_order(L.pl, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order);
-        else if (lds_set) m = bp_pyset_order(pairs, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order);
+        if (lds_pl) m = rb_pyset_order_wave(L.pl, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order, lane);
+        else if (lds_set) m = rb_pyset_order_wave(pairs, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order, lane);
         else {
             uint16_t *big = a.bigtab + (int64_t)ls * 2 * 131072;
-            m = bp_pyset_order(pairs, np, big, 131072, big + 131072, 131072, order);
+            m = rb_pyset_order_wave(pairs, np, big, 131072, big + 131072, 131072, order, lane);
         }
         if (m != np) flags |= RT_F_PAIR_OVERFLOW;
-        L.vals[2] = m < 0 ? 0 : m;
+        if (lane == 0) L.vals[2] = m < 0 ? 0 : m;
     }
     __syncthreads();
     RB_P(5)
