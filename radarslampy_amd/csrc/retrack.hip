@@ -1231,7 +1231,7 @@ __device__ int rb_build_node_wave(BpPt *pt, int start, int end, BpNode &nd, int 
 // keys at a time, one per lane), clearing a new table, listing the old table's keys in slot order at a resize, reading the final table
 // out.  The insertions themselves run on wave-uniform values (hash and key by v_readlane, uniform table reads), chunk by chunk up to
 // the next resize.  order doubles as the scratch list of a resize (it is the output: free until the end).
-template <typename ORD>
+template <bool TLDS, typename ORD>
 __device__ int rb_pyset_order_wave(const uint32_t *pairs, int np, uint16_t *tabA, int capA, uint16_t *tabB, int capB, ORD *order, int lane)
 {
     uint16_t *tab = tabA, *other = tabB;
@@ -1258,7 +1258,9 @@ __device__ int rb_pyset_order_wave(const uint32_t *pairs, int np, uint16_t *tabA
                 perturb >>= 5;
                 i = (uint32_t)(((uint64_t)i * 5 + 1 + perturb) & msk);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // (the next key reads what this one wrote)
+            // the next key reads what this one wrote: a wavefront's LDS operations execute in order (tables in LDS, TLDS); a table in
+            // global memory (more than 4 914 pairs) is written through before it is read again
+            if (!TLDS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         }
     };
     for (int p = 0; p < np;) {
@@ -1592,11 +1594,11 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     uint16_t *order = a.order + (int64_t)ls * (BP_MAX_PAIRS + 1);
     {
         int m;
-        if (lds_pl) m = rb_pyset_order_wave(L.pl, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order, lane);
-        else if (lds_set) m = rb_pyset_order_wave(pairs, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order, lane);
+        if (lds_pl) m = rb_pyset_order_wave<true>(L.pl, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order, lane);
+        else if (lds_set) m = rb_pyset_order_wave<true>(pairs, np, L.tabA, CP::CAPA, L.tabB, CP::CAPB, order, lane);
         else {
             uint16_t *big = a.bigtab + (int64_t)ls * 2 * 131072;
-            m = rb_pyset_order_wave(pairs, np, big, 131072, big + 131072, 131072, order, lane);
+            m = rb_pyset_order_wave<false>(pairs, np, big, 131072, big + 131072, 131072, order, lane);
         }
         if (m != np) flags |= RT_F_PAIR_OVERFLOW;
         if (lane == 0) L.vals[2] = m < 0 ? 0 : m;
