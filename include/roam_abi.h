@@ -279,6 +279,11 @@ int32_t roam_engine_map_get(roam_ctx *ctx, int32_t lane, int32_t index, double *
  * names_out receives n pointers to static strings. */
 int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap,
                                 int32_t *n);
+/* the timestamp events behind roam_engine_stage_times and the "doh_*" figures of roam_engine_kernel_avg / _kernel_chunk_ms: recorded by
+ * default (on = 1).  Thirteen timestamp packets in the back end's chain of dependent launches are nothing in a batch step and ~50 us of a
+ * single-sequence pair (1 600 -> 1 740 scan-pairs/s without motion distortion): the streaming driver switches them off (on = 0), after which
+ * those calls return ROAM_E_STATE.  ROAM_STAGE_EVENTS=0 / 1 in the environment of roam_engine_create overrides this call. */
+int32_t roam_engine_set_stage_events(roam_ctx *ctx, int32_t on);
 /* average in-step launch time (ms) of a front-end kernel ("ingest_peaks" | "warp_quantise" | "pyramid") over the
  * last `last_steps` steps (<= 64), from HIP event pairs recorded on the stream the kernel runs on; no
  * synchronisation happens inside the steps themselves.  "doh_integral" | "doh_det_maxima" (engines with

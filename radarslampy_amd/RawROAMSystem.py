@@ -87,7 +87,7 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
     ctx = ctx or _ffi.Context(int(os.environ.get("ROAM_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     eng = Engine(1, RING, ctx=ctx, rows=rows, stride=stride, payload_off=payload_off, clip=clip,
                  reject_outliers=flags.get("rejectOutliers", True), motion_distortion=flags.get("correctMotionDistortion", True),
-                 retrack_on_device=True)
+                 retrack_on_device=True, stage_events=False)
     if on_engine is not None:
         on_engine(eng)
     pinned = ctx.host_alloc((RING, rows, stride))

@@ -92,6 +92,7 @@ _SIGS = {
     "roam_engine_map_count": (C.c_int32, [_vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_map_get": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
     "roam_engine_stage_times": (C.c_int32, [_vp, _vp, _P(C.c_char_p), C.c_int32, _P(C.c_int32)]),
+    "roam_engine_set_stage_events": (C.c_int32, [_vp, C.c_int32]),
     "roam_engine_time_kernel": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_float), _P(C.c_double)]),
     "roam_engine_debug_detect": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp]),
     "roam_fmt_rotation": (C.c_int32, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double)]),

@@ -104,6 +104,8 @@ struct Engine {
     hipEvent_t ev_kfx[3] = {};                      // the PACK kernel of the exchange that read peak-ring slot i (the streams that overwrite its inputs wait for it)
     int kfx_last = -1;                              // slot of the latest pack
     hipEvent_t ev[ST_COUNT + 1] = {};
+    bool stage_ev_forced = false;                   // ... the environment said so
+    bool stage_ev = true;                           // record them (roam_engine_stage_times); ROAM_STAGE_EVENTS=0: ten timestamp packets fewer in the back end's chain
     hipEvent_t ev_join = nullptr, ev_pk0 = nullptr, ev_pk1 = nullptr;            // end of the front end (the back end waits for it) + the peak kernel's timing pair
     hipEvent_t ev_klt[4] = {}, ev_g4[4] = {};                // back-end milestones stage A of step N+3 waits for
     hipEvent_t ev_warp = nullptr;                            // end of stage A (stage B waits for it)
@@ -624,6 +626,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->results_host), sizeof(roam_lane_result) * (size_t)B * RES_RING, hipHostMallocDefault) != hipSuccess) {
         ROAM_SET_ERR(ctx, "engine: hipHostMalloc failed"); ok = false;
     }
+    { const char *se = getenv("ROAM_STAGE_EVENTS"); e->stage_ev = !(se && se[0] == '0'); e->stage_ev_forced = se && (se[0] == '0' || se[0] == '1'); }
     e->rt_on = cfg->retrack_on_device != 0;
     if (ok && e->rt_on) {
         // device-side feature (re)detection: DEFAULT_FEATURE_PARAMS of getFeatures.py:13-18, i.e. sigma = linspace(0.01, 10, 3)
@@ -1200,7 +1203,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipEventRecord(tr[4], sB));
     HIP_TRY(ctx, hipEventRecord(e->ev_join, sB));                         // end of stage B
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
     if (any_new) {
         // lanes that start a NEW sequence on this scan drop their features: nothing is tracked, the pose stays, and the retrack
         // branch detects the sequence's first features on this scan (appendNewFeatures(prevImgCart, empty), RawROAMSystem.py:150)
@@ -1212,24 +1215,24 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipLaunchKernelGGL(g1_good_kernel, dim3(B), dim3(256), 0, st, e->feat, e->feat_n, e->klt_next, e->klt_status, e->klt_err,
                        e->good_old, e->good_new, e->good_idx, e->good_n, KM);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_GRAPH], st));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_GRAPH], st));
     if (c.reject_outliers) {
         HIP_TRY(ctx, launch_consistency_graph(st, e->good_old, e->good_new, e->good_n, KM, KS, B, 0.5 / M_PER_PX, e->adj, nw));
-        HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
+        if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
         HIP_TRY(ctx, launch_max_clique(st, e->adj, e->good_n, KM, KS, nw, B, c.clique_node_limit, e->cq_stack, e->cq_mask, e->cq_n, e->cq_flags, e->cq_order));
     } else {
-        HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
+        if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_CLIQUE], st));
         hipLaunchKernelGGL(fill_mask_kernel, dim3(B), dim3(256), 0, st, e->cq_mask, e->good_n, e->cq_n, e->cq_flags);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_KABSCH], st));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_KABSCH], st));
     hipLaunchKernelGGL(g2_inliers_kernel, dim3(B), dim3(256), 0, st, e->good_old, e->good_new, e->good_idx, e->good_n, e->cq_mask,
                        e->kf_pose, e->kf_und, e->kf_und_tmp, e->kab_src, e->kab_tgt, e->p_w, e->p_jt, e->feat, e->in_n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, launch_kabsch(st, e->kab_src, e->kab_tgt, e->in_n, KM, KS, B, e->kab_out));
     hipLaunchKernelGGL(g3_init_transform_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->kab_out, e->pose, e->T_wj0, e->T_init, B);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_LM], st));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_LM], st));
     if (c.motion_distortion) {
         MdsProblemDesc P;
         P.T_wj0 = e->T_wj0; P.T_init = e->T_init; P.p_w = e->p_w; P.p_jt = e->p_jt; P.count = e->in_n;
@@ -1237,23 +1240,23 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         for (int i = 0; i < 5; i++) P.sigma5[i] = c.sigma5[i];
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_peaks, 0));
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
                        e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n[pb],
                        e->cq_flags, res_slot, e->scan_idx[pb], e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
                        e->map_cap);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_RETRACK], st));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_RETRACK], st));
     if (e->rt_on && e->rt_mode) {
         // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
         e->rt.res = res_slot;
         HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->rt_ev[e->nstep & 63], RT_TRACE_CHUNKS));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS));
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }
-    e->rt_ev_ok[e->nstep & 63] = e->rt_on && e->rt_mode;
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
+    e->rt_ev_ok[e->nstep & 63] = e->rt_on && e->rt_mode && e->stage_ev;
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_COUNT], st));
     HIP_TRY(ctx, hipEventRecord(e->ev_g4[k4], st));
     // per-step result record -> pinned host ring: roam_engine_step_results(step) waits for THIS copy only
     // (on the compute stream itself: a side stream waiting on an event here cost 11 % of the step rate - the extra stream
@@ -1371,11 +1374,19 @@ int32_t roam_engine_lane_image(roam_ctx *ctx, int32_t lane, int32_t level, uint8
     return ROAM_OK;
 }
 
+int32_t roam_engine_set_stage_events(roam_ctx *ctx, int32_t on)
+{
+    ENGINE();
+    if (!e->stage_ev_forced) e->stage_ev = on != 0;
+    return ROAM_OK;
+}
+
 int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names_out, int32_t cap, int32_t *n)
 {
     ENGINE();
     ARG_CHECK(ctx, ms_out && n && cap >= ST_COUNT);
     if (!e->stepped) { ROAM_SET_ERR(ctx, "no step recorded"); return ROAM_E_STATE; }
+    if (!e->stage_ev) { ROAM_SET_ERR(ctx, "stage events are off (ROAM_STAGE_EVENTS=0)"); return ROAM_E_STATE; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;

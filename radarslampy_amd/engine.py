@@ -15,8 +15,10 @@ class Engine:
     def __init__(self, lanes: int, pool_scans: int, ctx: _ffi.Context = None, rows=400, stride=3779, payload_off=11,
                  clip=2025, peaks_cap=65536, reject_outliers=True, motion_distortion=True, clique_node_limit=0,
                  sigma5=(4.0, 4.0, 1.0, 1.0, (5 * np.pi / 180) ** 2), retrack_on_device=False, retrack_slots=0,
-                 keyframe_trans_m=0.0, keyframe_rot_rad=0.0):
-        """keyframe_trans_m / keyframe_rot_rad: Map.isGoodKeyframe's thresholds (Mapping.py:13-15); 0 = the reference's 2.0 m / 0.2 rad"""
+                 keyframe_trans_m=0.0, keyframe_rot_rad=0.0, stage_events=True):
+        """keyframe_trans_m / keyframe_rot_rad: Map.isGoodKeyframe's thresholds (Mapping.py:13-15); 0 = the reference's 2.0 m / 0.2 rad.
+        stage_events=False: no timestamp events in the step (stage_times / the detection figures of kernel_avg are then unavailable):
+        what the single-sequence driver does - they are ~50 us of its pair"""
         self.ctx = ctx or _ffi.default_context()
         self.lib = self.ctx.lib
         cfg = _ffi.EngineCfg(lanes, rows, stride, payload_off, clip, pool_scans, peaks_cap, int(reject_outliers),
@@ -26,6 +28,8 @@ class Engine:
         self.lanes, self.pool_scans = lanes, pool_scans
         self.rows, self.stride = rows, stride
         self.ctx.check(self.lib.roam_engine_create(self.ctx.h, C.byref(cfg)))
+        if not stage_events:
+            self.ctx.check(self.lib.roam_engine_set_stage_events(self.ctx.h, 0))
         self._res = (_ffi.LaneResult * lanes)()
 
     def close(self):
