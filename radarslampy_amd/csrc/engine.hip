@@ -1185,22 +1185,22 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipStream_t sP = ctx->stream5;
     HIP_TRY(ctx, hipEventRecord(e->ev_idx, sA));
     HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_idx, 0));
-    HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sP));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sP));
-    HIP_TRY(ctx, hipEventRecord(tr[0], sP));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sP));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sP));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[0], sP));
     PeakSrc ps = {e->pool, (int64_t)e->rec_bytes, (int64_t)c.stride, c.payload_off, 1, e->scan_idx[pb]};
     HIP_TRY(ctx, launch_peaks(sP, ps, B, c.rows, c.clip, e->row_stage, e->stage_cap, e->row_count, e->peaks_out[pb], c.peaks_cap, e->peaks_n[pb]));
-    HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sP));
-    HIP_TRY(ctx, hipEventRecord(tr[5], sP));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sP));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[5], sP));
     HIP_TRY(ctx, hipEventRecord(e->ev_peaks, sP));
-    HIP_TRY(ctx, hipEventRecord(tr[1], sA));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[1], sA));
     HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride, e->warp_dark_zero));
-    HIP_TRY(ctx, hipEventRecord(tr[2], sA));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[2], sA));
     HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
     HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
-    HIP_TRY(ctx, hipEventRecord(tr[3], sB));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[3], sB));
     HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B, e->pyr_dark));
-    HIP_TRY(ctx, hipEventRecord(tr[4], sB));
+    if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[4], sB));
     HIP_TRY(ctx, hipEventRecord(e->ev_join, sB));                         // end of stage B
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_join, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_KLT], st));
@@ -1386,7 +1386,7 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
     ENGINE();
     ARG_CHECK(ctx, ms_out && n && cap >= ST_COUNT);
     if (!e->stepped) { ROAM_SET_ERR(ctx, "no step recorded"); return ROAM_E_STATE; }
-    if (!e->stage_ev) { ROAM_SET_ERR(ctx, "stage events are off (ROAM_STAGE_EVENTS=0)"); return ROAM_E_STATE; }
+    if (!e->stage_ev) { ROAM_SET_ERR(ctx, "stage events are off (roam_engine_set_stage_events)"); return ROAM_E_STATE; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;
@@ -1408,6 +1408,7 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
 {
     ENGINE();
     ARG_CHECK(ctx, name && last_steps >= 1 && avg_ms && n_used);
+    if (!e->stage_ev) { ROAM_SET_ERR(ctx, "stage events are off (roam_engine_set_stage_events)"); return ROAM_E_STATE; }
     int k = !strcmp(name, "ingest_peaks") ? 0 : (!strcmp(name, "warp_quantise") ? 1 : (!strcmp(name, "pyramid") ? 2 : -1));
     // the two image-scale kernels of the detection: the FIRST chunk of every step (min(retrack_slots, lanes flagged in that step)
     // detections; steps without device-side detection do not count) - roam_engine_kernel_chunk_ms has every chunk
