@@ -1165,10 +1165,31 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64
 #endif
     // ---- phase 2: the first clique of size omega in networkx.find_cliques order (nx_walk)
     uint64_t REC = WIT;
+    // ... unless there is only one: every clique of size omega lies in the (omega - 1)-core of the graph (vertices with at least omega - 1
+    // neighbours inside it, to a fixed point), and a core of exactly omega vertices IS that clique - the witness - whatever the order.
+    // A few degree passes (~1 us each) against a walk of 100+ us: a quarter of the real / bench-like pairs (5 of 16 lone sets).
+    bool unique = false;
+#ifndef NX_EXP_NOCORE
+    if (c.complete && omega > 1) {
+        uint64_t P = ALL;
+        for (;;) {
+            const int cnt = bs_count(P);
+            if (cnt <= omega) { unique = cnt == omega; break; }
+            if (lane < 16) c.sw[lane] = P;
+            WSYNC();
+            uint64_t RM = 0, UN = 0, PE = 0;
+            int key = 0x7fffffff;
+            cq_degrees(c, c.sw, 0, nw, omega - 1, cnt, RM, UN, PE, key);
+            WSYNC();
+            if (!__ballot(RM != 0)) break;
+            P &= ~RM;
+        }
+    }
+#endif
 #ifdef NX_EXP_NOWALK
     if (false) {
 #else
-    if (c.complete && omega > 0) {
+    if (c.complete && omega > 0 && !unique) {
 #endif
         uint64_t RF = 0;
         { NX_T0 if (nx_walk<TWO>(c, L, Kb, ALL, omega, WIT, RF)) REC = RF; NX_T1(11) }
