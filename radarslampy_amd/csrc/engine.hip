@@ -121,6 +121,12 @@ struct Engine {
     static constexpr bool warp_dark_zero = true;   // the pyramids are zero-filled at creation and level 0 is written by the warp only:
                                                     // its tiles beyond the maximum range are never stored (0.6 ms of 11.4 per 4096 scans)
     bool ev_ok = false, stepped = false, uploads_pending = false;
+    // asynchronous uploads are numbered; a step waits for the upload that last wrote one of ITS scans, not for the newest one - the
+    // newest waits (roam_engine_fence) for the steps before it, and a front end that waited for it ran after the previous step's back end
+    // instead of beside it (the single-sequence driver: ~170 us of every pair)
+    uint64_t up_seq = 0, up_waited = 0;
+    std::vector<uint64_t> slot_seq;
+    hipEvent_t ev_up_ring[16] = {};
     std::vector<int> lane_k;            // host-side upper bound of each lane's feature count
     // device-side retracks (mode 1) grow a lane to at most 60 + 256 features without the host knowing which lane; a step in
     // mode 2 re-detects on EVERY lane, whatever it holds: the bound of every lane then grows by the 256 the append may add
@@ -540,6 +546,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     if (e->st_comm) { hipStreamSynchronize(e->st_comm); hipStreamDestroy(e->st_comm); }
     for (auto &ev : e->ev_kfx) if (ev) hipEventDestroy(ev);
     if (e->ev_pool) hipEventDestroy(e->ev_pool);
+    for (auto &ev : e->ev_up_ring) if (ev) hipEventDestroy(ev);
     hipStreamSynchronize(ctx->stream2);
     hipStreamSynchronize(ctx->stream4);
     delete e;
@@ -683,6 +690,9 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     }
     for (auto &ev : e->ev_res)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    e->slot_seq.assign((size_t)cfg->pool_scans, 0);
+    for (auto &ev : e->ev_up_ring)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
     if (hipEventCreateWithFlags(&e->ev_pool, hipEventDisableTiming) != hipSuccess) {
         ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
     }
@@ -760,6 +770,9 @@ int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t
                        e->pool + (size_t)pool_idx0 * e->rec_bytes, (int64_t)e->rec_bytes, e->cfg.rows, e->cfg.stride, width);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_up, ctx->stream3));
+    e->up_seq++;
+    for (int i = 0; i < n; i++) e->slot_seq[(size_t)pool_idx0 + i] = e->up_seq;
+    HIP_TRY(ctx, hipEventRecord(e->ev_up_ring[e->up_seq & 15], ctx->stream3));
     e->uploads_pending = true;
     return ROAM_OK;
 }
@@ -1174,7 +1187,16 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_klt[w4], 0));
     HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_g4[w4], 0));
     // (lane initialisation, retracks and synchronous uploads finish on the host before a step is enqueued)
-    if (e->uploads_pending) { HIP_TRY(ctx, hipStreamWaitEvent(sA, ctx->ev_up, 0)); e->uploads_pending = false; }
+    if (e->uploads_pending) {
+        uint64_t need = 0;
+        for (int b = 0; b < B; b++) need = std::max(need, e->slot_seq[(size_t)(scan_idx[b] & ~ROAM_STEP_NEW_SEQUENCE)]);
+        if (need > e->up_waited) {
+            if (e->up_seq - need < 16) HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_up_ring[need & 15], 0));
+            else { HIP_TRY(ctx, hipStreamWaitEvent(sA, ctx->ev_up, 0)); need = e->up_seq; }      // (its event has been reused: the newest covers it)
+            e->up_waited = need;
+        }
+        if (e->up_waited == e->up_seq) e->uploads_pending = false;
+    }
     if (e->pool_dirty) { HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_pool, 0)); e->pool_dirty = false; }   // device-to-device record copies
     int32_t *hs = e->scan_host + (size_t)pb * 2 * B;
     if (e->nstep >= 3) HIP_TRY(ctx, hipEventSynchronize(e->ev_g4[w4]));   // the staging slot's last copy has long been consumed
