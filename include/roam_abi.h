@@ -209,7 +209,8 @@ int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *
 /* raw-record ingest (reference parseData.py:160-226 loads one PNG per frame; here n records of rows x stride u8,
  * `host_stride` bytes apart in PINNED host memory, are copied to pool slots pool_idx0.. (only the payload_off + clip
  * bytes of every row that the path reads cross PCIe) on a copy stream that
- * overlaps the compute stream).  roam_engine_step waits for every upload enqueued before it;
+ * overlaps the compute stream).  roam_engine_step waits for the uploads that wrote the pool slots IT reads (the newest of them; not for
+ * uploads of other slots enqueued meanwhile - those may themselves be waiting, behind a fence, for earlier steps);
  * roam_engine_fence makes later uploads wait for the steps enqueued so far (double-buffered pools). */
 /* host_records must be pinned / registered host memory (the copy kernel reads it from the GPU): a pageable pointer is refused
  * with ROAM_E_ARG */

@@ -746,7 +746,7 @@ int32_t roam_engine_upload_scan(roam_ctx *ctx, int32_t pool_idx, const uint8_t *
 // f2 (raw-record ingest): records stream from PINNED host memory on the copy stream while the main
 // stream computes.  Protocol for a double-buffered pool (halves A/B):
 //   roam_engine_upload_scans_async(half B)   - copy stream; starts after the last roam_engine_fence()
-//   roam_engine_step(scans of half A)        - main stream; first waits for every upload enqueued so far
+//   roam_engine_step(scans of half A)        - main stream; first waits for the uploads of the slots it reads
 //   roam_engine_fence()                      - uploads enqueued from now on wait for the steps enqueued so far
 int32_t roam_engine_upload_scans_async(roam_ctx *ctx, int32_t pool_idx0, int32_t n, const uint8_t *host_records, int64_t host_stride)
 {
