@@ -1252,8 +1252,10 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
                        e->kf_pose, e->kf_und, e->kf_und_tmp, e->kab_src, e->kab_tgt, e->p_w, e->p_jt, e->feat, e->in_n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, launch_kabsch(st, e->kab_src, e->kab_tgt, e->in_n, KM, KS, B, e->kab_out));
-    hipLaunchKernelGGL(g3_init_transform_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->kab_out, e->pose, e->T_wj0, e->T_init, B);
-    HIP_TRY(ctx, hipGetLastError());
+    if (c.motion_distortion) {                                           // (T_wj0 / T_init feed the LM solve only)
+        hipLaunchKernelGGL(g3_init_transform_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->kab_out, e->pose, e->T_wj0, e->T_init, B);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_LM], st));
     if (c.motion_distortion) {
         MdsProblemDesc P;
