@@ -59,6 +59,37 @@ def test_engine_matches_oracle_pipeline(sequences, md, reject):
     ctx.close()
 
 
+def test_engine_without_stage_events_gives_the_same_results():
+    """roam_engine_set_stage_events(0) (what the single-sequence driver does): the step's timestamp events are not recorded - same
+    results record for record, stage_times / kernel_avg refuse with a state error instead of reading stale events"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, _ = synth.make_sequence(31, 4, n_movers=8)
+    out = []
+    for ev in (True, False):
+        ctx = _ffi.Context(0)
+        eng = Engine(2, 4, ctx=ctx, retrack_on_device=True, stage_events=ev)
+        for t in range(4):
+            eng.upload_scan(t, recs[t])
+        for b in range(2):
+            eng.init_lane_detect(b, 0, poses[0])
+        rows = []
+        for t in range(1, 4):
+            eng.step([t, t])
+            rows.append([(r["n_tracked"], r["n_good"], r["n_inliers"], tuple(r["pose"])) for r in eng.results()])
+        if ev:
+            assert "klt" in eng.stage_times()
+        else:
+            with pytest.raises(_ffi.RoamError):
+                eng.stage_times()
+            with pytest.raises(_ffi.RoamError):
+                eng.kernel_avg("warp_quantise", 1)
+        out.append(rows)
+        eng.close()
+        ctx.close()
+    assert out[0] == out[1]
+
+
 def test_engine_argument_errors():
     from radarslampy_amd import _ffi
     from radarslampy_amd.engine import Engine

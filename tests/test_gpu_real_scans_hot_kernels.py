@@ -2,11 +2,12 @@
 
 The one-lane real-scan tests (test_gpu_tiny_traj.py, test_gpu_retrack.py::test_device_retrack_on_the_reference_real_scans) hold
 fewer than 200 detections per chunk and therefore take the small-chunk detection kernels.  Here the 11 real data/tiny payloads
-(tests/golden/tiny_track.npz) are played by 2 x 224 lanes - 224 forward from the ground-truth start pose (the run the reference
-printed into img/roam_mapping/tiny_traj, getFeatures.py:22-95 / parseData.py:100-135 / outlierRejection.py:63-75) and 224
-backward - with retrack_slots = 448, so that EVERY detection chunk holds >= 200 detections and the engine's batch path runs on
+(tests/golden/tiny_track.npz) are played by 2 x 256 lanes - 256 forward from the ground-truth start pose (the run the reference
+printed into img/roam_mapping/tiny_traj, getFeatures.py:22-95 / parseData.py:100-135 / outlierRejection.py:63-75) and 256
+backward - with retrack_slots = 512, so that EVERY detection chunk holds >= 200 detections and the engine's batch path runs on
 real data: the one-sweep / fused detection kernels, rt_blobs_kernel<true>, the batched SSC, warp_gather_kernel + the pyramid
-kernels at a few hundred lanes.  Per lane and per step, against oracle.OdometryPipeline: features bit for bit, counts, poses at
+kernels at a few hundred lanes; and 512 problems per launch is where the engine starts the longest clique / blob-bookkeeping problems
+first (cq_order_kernel).  Per lane and per step, against oracle.OdometryPipeline: features bit for bit, counts, poses at
 1e-4 m / 1e-5 rad; frames 1-3 of the forward lanes against the numbers the reference itself printed; the warped + quantised image
 and its three pyramid levels byte for byte."""
 import os
@@ -19,7 +20,7 @@ import oracle
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 PRINT = 1.1e-3
-HALF = 224
+HALF = 256
 
 
 def _detect(cart):
@@ -48,7 +49,7 @@ def test_batch_kernels_on_the_reference_real_scans():
         feat0 = oracle.append_dedupe(np.empty((0, 2)), _detect(cart0))
         assert 150 <= len(feat0) <= 260
         pipes.append(oracle.OdometryPipeline(rec0, feat0, pose0[g], detect=_detect, payload_off=0, clip=clip))
-    for b in range(B):                                                       # 448 first detections in one chunk
+    for b in range(B):                                                       # 512 first detections in one chunk
         assert np.array_equal(eng.lane_features(b), pipes[grp[b]].blobCoord), b
     check_img = (0, 1, HALF - 1, HALF, B - 1)
     n_rt = [0, 0]
@@ -56,7 +57,7 @@ def test_batch_kernels_on_the_reference_real_scans():
         eng.step([order[g][k] for g in grp])
         res = eng.results()
         want = [pipes[g].step(np.ascontiguousarray(pay[order[g][k]])) for g in range(2)]
-        # every chunk of this step is either empty or holds >= 224 detections (the batch detection path)
+        # every chunk of this step is either empty or holds >= 256 detections (the batch detection path)
         for name in ("doh_integral", "doh_det_maxima"):
             m = eng.kernel_chunk_ms(name, 1)
             assert m.shape[0] == 1 and (m[0] > 0.0).any(), (k, name, m)
