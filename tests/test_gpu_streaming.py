@@ -36,7 +36,7 @@ def sequence(distorted):
     return _SEQ[distorted]
 
 
-def _run(recs, pose0, md, pipelined, probe_every=0):
+def _run(recs, pose0, md, pipelined, probe_every=0, ahead=3):
     """-> poses (N, 3), final (features, keyframe), probes {step: (features, keyframe, pose) BEFORE that step}"""
     from radarslampy_amd import _ffi
     from radarslampy_amd.engine import Engine
@@ -51,7 +51,7 @@ def _run(recs, pose0, md, pipelined, probe_every=0):
         pinned[k % RING] = recs[k]
         eng.upload_scans_async(k % RING, pinned[k % RING], n=1)
 
-    for k in range(4):
+    for k in range(max(ahead, 1) + 1):
         up(k)
     eng.synchronize()
     eng.init_lane_detect(0, 0, pose0)
@@ -61,7 +61,11 @@ def _run(recs, pose0, md, pipelined, probe_every=0):
             probes[k] = (eng.lane_features(0), eng.live_keyframe(0), r["pose"].copy())
         eng.step([k % RING])
         eng.fence()
-        if k + 3 < n:
+        if k + ahead + 1 < n and ahead == 0:
+            up(k + 1)                                        # the NEXT step's own scan, behind the fence: that step has to wait for it
+            pinned[(k + 4) % RING] = recs[min(k + 4, n - 1)]
+            eng.upload_scans_async((k + 4) % RING, pinned[(k + 4) % RING], n=1)      # ... and not for this one, of a slot it does not read
+        elif k + 3 < n and ahead:
             up(k + 3)
         if pipelined:
             if k - 3 >= 0:
@@ -78,6 +82,18 @@ def _run(recs, pose0, md, pipelined, probe_every=0):
     eng.close()
     ctx.close()
     return poses, flags, final, probes
+
+
+def test_a_step_waits_for_the_uploads_of_its_own_scans():
+    """roam_engine_step waits for the newest asynchronous upload among the pool slots IT reads (not for every upload enqueued so far: that
+    one may sit behind a fence).  Frame k + 1 uploaded right after step k - behind the fence, with a later upload of another slot queued
+    after it - gives the results of the run that uploads three frames ahead, record for record."""
+    recs, poses = sequence(True)
+    recs = recs[:60]
+    a = _run(recs, poses[0], True, True)
+    b = _run(recs, poses[0], True, True, ahead=0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2][0], b[2][0])
 
 
 @pytest.mark.parametrize("md", [False, True])
