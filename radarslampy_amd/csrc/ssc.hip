@@ -78,7 +78,7 @@ __device__ __forceinline__ void ssc_body(const double *__restrict__ kp, int B, i
                 const int j = __ffsll((long long)alive) - 1;
                 accepted |= 1ull << j;
                 alive &= ~(1ull << j);
-                const int rj = __shfl(r, j), qj = __shfl(q, j);
+                const int rj = __builtin_amdgcn_readlane(r, j), qj = __builtin_amdgcn_readlane(q, j);   // (j is wave-uniform: v_readlane, not ds_bpermute)
                 int dr = r - rj, dq = q - qj;
                 dr = dr < 0 ? -dr : dr; dq = dq < 0 ? -dq : dq;
                 const uint64_t kill = __ballot(lane > j && dr <= w && dq <= w);
