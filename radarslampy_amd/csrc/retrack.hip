@@ -211,7 +211,11 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #ifndef RI_LDS_PAD
 #define RI_LDS_PAD 0                        // (occupancy experiments: profiles/build_variant.py)
 #endif
-#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
+#ifndef RI_SINGLE_BUF
+#define RI_SINGLE_BUF 0                     // 1: ONE tile buffer (half the LDS: four workgroups per CU), the taps of A(i+1) overlap B(i), the tile accesses do not
+#endif
+#define RI_NBUF (RI_SINGLE_BUF ? 1 : 2)
+#define RI_LDS_BYTES (RI_NBUF * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
 struct __attribute__((packed)) RtU16 { uint16_t v; };
 struct __attribute__((packed)) RtU32 { uint32_t v; };
 #ifndef RI_BOX
@@ -350,10 +354,8 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             if (b.inside) load_pieces(b, 0);
 #endif
         };
-        auto A = [&](int band, int g) {
-            const int c = g * 64 * RI_WAVES + 64 * wave + lane;
-            Tile &tl = tiles[((band * RI_GROUPS + g) & 1) * RI_WAVES + wave];
-            float v[RI_ROWS];
+        float v[RI_ROWS];                                                  // the pixels of the phase A1 has prepared for A2
+        auto A1 = [&](int band, int g) {
             // The polar footprint of the wave's 64 x 16 pixel patch is a small box (range span x azimuth span, a few hundred bytes):
             // it is copied into LDS with a handful of coalesced row loads (16 lanes per polar row, four rows per instruction) and
             // the 4 taps per pixel become LDS byte reads; per-lane byte gathers from global memory (two 16-bit loads per pixel,
@@ -420,6 +422,10 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                     if (i1 + 1 < nbands * RI_GROUPS) fetch_ext(i1 + 1);
                 }
             }
+        };
+        auto A2 = [&](int band, int g) {
+            const int c = g * 64 * RI_WAVES + 64 * wave + lane;
+            Tile &tl = tiles[(RI_SINGLE_BUF ? 0 : ((band * RI_GROUPS + g) & 1)) * RI_WAVES + wave];
             {
                 // acc[0] is always the running sum of the CURRENT group's column: the groups come round in order, so the array is
                 // rotated by one after every phase (8 register moves; a group-indexed array was kept in scratch memory by the
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         };
         auto C = [&](int band, int g) {
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
-            const Tile &tl = tiles[((band * RI_GROUPS + g) & 1) * RI_WAVES + wave];
+            const Tile &tl = tiles[(RI_SINGLE_BUF ? 0 : ((band * RI_GROUPS + g) & 1)) * RI_WAVES + wave];
             if (c < W) {
                 double *q = S + (int64_t)band * RI_ROWS * SP + c;
                 const int nk = min(RI_ROWS, H - band * RI_ROWS);
@@ -455,15 +461,27 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         fetch_ext(0);
         prefetch_box();
         if (nphase > 1) fetch_ext(1);
-        A(0, 0);
+        A1(0, 0);
+#if RI_SINGLE_BUF
+#pragma unroll 1
+        for (int i = 0; i < nphase; i++) {
+            A2(i / RI_GROUPS, i % RI_GROUPS);
+            __syncthreads();                                               // tile i is complete: B(i) runs ..
+            if (i + 1 < nphase) A1((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS);   // .. beside the taps of phase i + 1 (registers only)
+            __syncthreads();                                               // B(i) is complete
+            C(i / RI_GROUPS, i % RI_GROUPS);
+        }
+#else
+        A2(0, 0);
 #pragma unroll 1
         for (int i = 0; i < nphase; i++) {
             __syncthreads();                                               // A(i) and B(i-1) are complete
             if (i > 0) C((i - 1) / RI_GROUPS, (i - 1) % RI_GROUPS);
-            if (i + 1 < nphase) A((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS);
+            if (i + 1 < nphase) { A1((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS); A2((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS); }
         }
         __syncthreads();
         C(nbands - 1, RI_GROUPS - 1);
+#endif
     } else {
         // ------------------------------------------------------------------------------------ the row wave: B(i)
         for (int band = 0; band < nbands; band++) {
@@ -471,9 +489,9 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             const bool live = lane < RI_ROWS && band * RI_ROWS + lane < H;
             for (int g = 0; g < RI_GROUPS; g++) {
                 __syncthreads();
-                if (!live) continue;
+                if (live) {
                 const int C0 = g * 64 * RI_WAVES, ncols = min(64 * RI_WAVES, W - C0);
-                Tile *tg = tiles + ((band * RI_GROUPS + g) & 1) * RI_WAVES;
+                Tile *tg = tiles + (RI_SINGLE_BUF ? 0 : ((band * RI_GROUPS + g) & 1)) * RI_WAVES;
                 int j = 0;
                 if (ncols >= 16) {
                     // two batches of eight columns in flight: while one is added up (eight dependent float64 additions) and written
@@ -506,9 +524,15 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                     carry = __dadd_rn(carry, *q);
                     *q = carry;
                 }
+                }
+#if RI_SINGLE_BUF
+                __syncthreads();                                           // (outside the lanes' branch: one barrier per wave)
+#endif
             }
         }
+#if !RI_SINGLE_BUF
         __syncthreads();
+#endif
     }
 }
 

@@ -225,7 +225,7 @@ template <int M> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
 // written with one 16-byte LDS store (the LDS row pitch bp is a multiple of 4 floats).  wave wvs takes the row
 // groups wvs, wvs+4, ...; the U scans' loads are issued before the first is consumed.
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
-template <int U, bool CHK>
+template <int U, bool CHK, bool RAWK = false>
 __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t lane_stride,
                                          const int32_t *__restrict__ lane_index, int l, int64_t row_stride, int rows,
                                          int cols, int mnx, int mny, int bw, int bp, int bh, int elems, int wvs, int lane,
@@ -252,15 +252,38 @@ __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t
                 float4 v;
                 // (CHK: the box reaches past the scan's last range bin - those samples are zero; most boxes do not, and are spared the
                 // four compares and selects per dword)
-                v.x = (!CHK || x0 < cols) ? code_to_f32(raw[u] & 255u) : 0.f;
-                v.y = (!CHK || x0 + 1 < cols) ? code_to_f32((raw[u] >> 8) & 255u) : 0.f;
-                v.z = (!CHK || x0 + 2 < cols) ? code_to_f32((raw[u] >> 16) & 255u) : 0.f;
-                v.w = (!CHK || x0 + 3 < cols) ? code_to_f32(raw[u] >> 24) : 0.f;
+                // RAWK: the codes as they are (integer blend, below): one v_cvt_f32_ubyteN per sample
+                v.x = (!CHK || x0 < cols) ? (RAWK ? (float)(raw[u] & 255u) : code_to_f32(raw[u] & 255u)) : 0.f;
+                v.y = (!CHK || x0 + 1 < cols) ? (RAWK ? (float)((raw[u] >> 8) & 255u) : code_to_f32((raw[u] >> 8) & 255u)) : 0.f;
+                v.z = (!CHK || x0 + 2 < cols) ? (RAWK ? (float)((raw[u] >> 16) & 255u) : code_to_f32((raw[u] >> 16) & 255u)) : 0.f;
+                v.w = (!CHK || x0 + 3 < cols) ? (RAWK ? (float)(raw[u] >> 24) : code_to_f32(raw[u] >> 24)) : 0.f;
                 *reinterpret_cast<float4 *>(drow + u * elems) = v;
             }
         }
     }
 }
+
+// ---- exact blend (round 6).  The KLT input is trunc(v * 255) with v = ((s00 w00 + s01 w01) + s10 w10) + s11 w11 in float32, s = code / 255
+// and the weights multiples of 2^-10 that sum to 1.  With integer weights W = 1024 w the exact value of v * 255 is E = sum(W k) / 1024, a
+// multiple of 2^-10, and the float32 chain (one rounding for the decode, one per product, three for the sums, one for the scaling, all
+// operands non-negative) stays within 6.001 * 2^-24 * E < 9.2e-5 of it - a tenth of 2^-10.  So whenever E is NOT an integer the truncated
+// float equals floor(E) = sum(W k) >> 10, whatever the roundings did; only a sum that is an exact non-zero multiple of 1024 (the float may
+// land just below the integer: one pixel in ~1024) needs the float chain, and a sum of zero is zero either way.
+// sum(W k) is formed in FLOAT32 all the same - 64 W (at most 2^16) and k (at most 255) are integers, every product and partial sum is an
+// integer below 2^24, so three v_fma_f32 after one v_mul_f32 are exact in any order - because float32 multiply-adds are the cheapest
+// vector instructions on this chip (SIMD-32: half the cycles of an integer instruction; a first version with v_dot4_u32_u8 on packed codes
+// and 24-bit integer multiply-adds was bit-identical and took 14.3 ms against 10.5).  The box holds the codes as floats (one
+// v_cvt_f32_ubyteN per sample instead of the three-instruction exact quotient by 255), v_cvt_u32_f32 turns the sum into the integer
+// 64 sum(W k): byte 2 is the pixel and "multiple of 1024" reads "low half zero" (v_min3_u16 over a thread's four pixels).  Flagged pixels
+// go to a per-wave list and are recomputed by the float32 chain from global memory after the dword stores they correct (same wave, after
+// s_waitcnt vmcnt(0)): at the end of the workgroup, or earlier when the list runs full.
+#ifndef WG_INT_BLEND
+#define WG_INT_BLEND 0                      // NOT the default: bit-identical on every test, and slower (profiles/r06_warp_exact_blend.txt)
+#endif
+#ifndef WG_DIAG
+#define WG_DIAG 0                           // timing experiments (wrong bytes): 1 = no fill, 2 = no blend loop
+#endif
+#define WG_FIX_CAP 320                      // entries per wave; flushed at 64 before a pass of at most 256 new ones
 
 __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__restrict__ map, const uint8_t *__restrict__ pool,
                                                           int64_t lane_stride, int64_t row_stride, int payload_off,
@@ -290,6 +313,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     };
     int ixv[4], iyv[4];
     float w00[4], w01[4], w10[4], w11[4];
+    uint32_t mw[4];
     bool in0[4];
     int mnx = 0x7fffffff, mxx = -1, mny = 0x7fffffff, mxy = -1;
 #pragma unroll
@@ -302,7 +326,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
         const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
         w00[j] = __fmul_rn(wy0, wx0); w01[j] = __fmul_rn(wy0, wx1);
         w10[j] = __fmul_rn(wy1, wx0); w11[j] = __fmul_rn(wy1, wx1);
-        ixv[j] = ix; iyv[j] = iy;
+        ixv[j] = ix; iyv[j] = iy; mw[j] = m;
         in0[j] = ok && ix < cols;
         if (in0[j]) { mnx = min(mnx, ix); mxx = max(mxx, ix); mny = min(mny, iy); mxy = max(mxy, iy); }
     }
@@ -382,6 +406,104 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
         }
         return;
     }
+#if WG_INT_BLEND
+    // box path, exact blend (see above); branch-free: pixels outside the scan get zero weights and offset 0
+    static_assert(WG_LB <= 32, "a list entry holds the scan in five bits");
+    __shared__ uint16_t fixl[4][WG_FIX_CAP];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!in0[j]) { w00[j] = w01[j] = w10[j] = w11[j] = 0.f; off0[j] = off1[j] = 0; }
+        w00[j] = __fmul_rn(w00[j], 65536.f); w01[j] = __fmul_rn(w01[j], 65536.f);       // 64 W: integers up to 2^16
+        w10[j] = __fmul_rn(w10[j], 65536.f); w11[j] = __fmul_rn(w11[j], 65536.f);
+    }
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const bool chk = mnx + bp > cols;                 // some staged column lies past the last range bin (wave-uniform)
+    const int per = max(1, min(WG_LB, WG_BOX_ELEMS / elems));
+    uint16_t *fl = fixl[wvs];
+    int nfix = 0;                                     // entries in this wave's list (wave-uniform)
+    const uint64_t below = (1ull << lane) - 1ull;
+    // the float32 chain for the listed pixels (entry = q | j << 5 | lane << 7: scan l0 + q, row 4 wv + j of the tile, column lane)
+    auto fix_pixels = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): the dword stores these bytes correct have left
+        for (int i = lane; i < nfix; i += 64) {
+            const uint32_t e = fl[i];
+            const int q = e & 31, j = (e >> 5) & 3, ln = e >> 7;
+            const int xx = bx_ * WG_TW + ln, yy = y0 + wvs * 4 + j, l = l0 + q;
+            const uint32_t m = map[(int64_t)yy * W + xx];
+            const int ix = m & 4095, iy = (m >> 12) & 1023;
+            const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+            const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+            int r0 = iy - 1, r1 = iy;
+            if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
+            if (r1 >= rows) r1 -= rows;
+            const uint8_t *p = pool + ((lane_index ? (int64_t)lane_index[l] : (int64_t)l) * lane_stride + payload_off);
+            const uint8_t *q0 = p + r0 * (int)row_stride + ix, *q1 = p + r1 * (int)row_stride + ix;
+            const bool i1 = ix + 1 < cols;
+            const float s00 = code_to_f32(q0[0]), s01 = i1 ? code_to_f32(q0[1]) : 0.f;
+            const float s10 = code_to_f32(q1[0]), s11 = i1 ? code_to_f32(q1[1]) : 0.f;
+            float v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
+            v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
+            v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
+            v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
+            cart_u8[(int64_t)l * u8_lane_stride + (int64_t)yy * W + xx] = (uint8_t)quant_u8_unit(v);
+        }
+        nfix = 0;
+    };
+    for (int lb = l0; lb < l1; lb += per) {
+        const int nq = min(per, l1 - lb);
+        for (int qb = (WG_DIAG == 1 ? nq : 0); qb < nq;) {
+            const int rem = nq - qb;
+            const uint8_t *sp = pool + payload_off;
+            float *bq = box + qb * elems;
+#define WG_FILL(U_) { if (chk) box_fill<U_, true, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); \
+                      else box_fill<U_, false, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += U_; }
+            if (rem >= 8 && WG_FILL_U >= 8) WG_FILL(8)
+            else if (rem >= 4 && WG_FILL_U >= 4) WG_FILL(4)
+            else if (rem >= 2 && WG_FILL_U >= 2) WG_FILL(2)
+            else WG_FILL(1)
+#undef WG_FILL
+        }
+        __syncthreads();
+        uint8_t *dq = dst + (int64_t)lb * u8_lane_stride;          // this thread's dword in scan lb, advanced per scan
+        for (int q = (WG_DIAG == 2 ? nq : 0); q < nq; q++) {
+            const float *bx = box + q * elems;
+            uint32_t sm[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x2 ta = f32x2{bx[off0[j]], bx[off0[j] + 1]}, tb = f32x2{bx[off1[j]], bx[off1[j] + 1]};   // one ds_read2_b32 each
+                float e = __fmul_rn(ta.x, w00[j]);                                 // exact: integers below 2^24
+                e = __fmaf_rn(ta.y, w01[j], e);
+                e = __fmaf_rn(tb.x, w10[j], e);
+                e = __fmaf_rn(tb.y, w11[j], e);
+                sm[j] = (uint32_t)e;                                               // 64 * sum(W k)
+            }
+            uint32_t mn;
+            asm("v_min3_u16 %0, %1, %2, %3" : "=v"(mn) : "v"(sm[0]), "v"(sm[1]), "v"(sm[2]));
+            asm("v_min_u16 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(sm[3]));
+            if (WG_DIAG != 3 && WG_DIAG != 4 && __builtin_expect(__ballot((mn & 0xffffu) == 0u) != 0ull, 0)) {
+                // (rare) some pixel's sum has a zero low half: list the non-zero ones for the float chain
+                if (nfix > WG_FIX_CAP - 256) fix_pixels();
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool f = (sm[j] & 0xffffu) == 0u && sm[j] != 0u;
+                    const uint64_t bal = __ballot(f);
+                    if (f) fl[nfix + __popcll(bal & below)] = (uint16_t)((lb - l0 + q) | (j << 5) | (lane << 7));
+                    nfix += __popcll(bal);
+                }
+            }
+            // byte 2 of each sum is the pixel
+            const uint32_t pk = __builtin_amdgcn_perm(sm[1], sm[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sm[3], sm[2], 0x06020c0cu);
+            const uint32_t v0 = quad_bcast<0>(pk), v1 = quad_bcast<1>(pk), v2 = quad_bcast<2>(pk), v3 = quad_bcast<3>(pk);
+            const uint32_t t01 = __builtin_amdgcn_perm(v1, v0, psel), t23 = __builtin_amdgcn_perm(v3, v2, psel);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(pull << 2, (int)(t01 | (t23 << 16)));
+            if (sok) *reinterpret_cast<uint32_t *>(dq) = o;
+            dq += u8_lane_stride;
+        }
+        __syncthreads();
+    }
+    if (WG_DIAG != 4 && nfix > 0) fix_pixels();
+}
+#else
     // box path, written branch-free: pixels outside the scan get zero weights and offset 0, loads
     // past the end of a row / past the last scan of the pass are clamped onto a valid duplicate
     f32x2 wa[4], wb[4];
@@ -442,6 +564,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
         __syncthreads();
     }
 }
+
+#endif
 
 // requires W % 4 == 0, u8_lane_stride % 4 == 0, rows * row_stride + cols < 2^31
 hipError_t launch_warp_gather(hipStream_t st, const uint32_t *map, WarpSrc src, int B, int rows, int cols,
