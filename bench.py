@@ -828,15 +828,18 @@ def stream_measure(recs, poses, md, ctx):
 
 
 def stream_png_measure(recs, poses, md, ctx, workers):
-    """8f-f2 on the clock: the same sequence from PNG FILES - inflate on a pool of host threads that runs ahead of the loop
-    (parseData.prefetchRadarRecords), staging copy, H2D, step.  The files are written first (untimed; tmpfs when there is one)."""
+    """8f-f2 on the clock: the same sequence from PNG FILES - zlib inflate + un-filter on the library's pool of host threads
+    (parseData.NativeRecordReader -> roam_png_pool_*) straight into a ring of pinned slots, H2D from those slots, step.  The files are
+    written first (untimed; tmpfs when there is one).  Beside it, for the record: round 5's pool of Pillow processes with its
+    shared-memory ring, and one Pillow decode on the feeding thread (round 4)."""
     import shutil
     import tempfile
     from PIL import Image
-    from radarslampy_amd.RawROAMSystem import stream_records
-    from radarslampy_amd.parseData import RecordDecodePool, prefetchRadarRecords, readRadarRecord
+    from radarslampy_amd.RawROAMSystem import RING, default_decode_workers, stream_records
+    from radarslampy_amd.parseData import NativeRecordReader, RecordDecodePool, prefetchRadarRecords, readRadarRecord
     n = len(recs)
     flags = {"rejectOutliers": True, "correctMotionDistortion": md}
+    w = workers if workers > 0 else default_decode_workers()
     d = tempfile.mkdtemp(prefix="roam_png_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         paths = []
@@ -844,40 +847,39 @@ def stream_png_measure(recs, poses, md, ctx, workers):
             paths.append(os.path.join(d, f"{i:06d}.png"))
             Image.fromarray(r).save(paths[-1], compress_level=6)
         size = float(np.mean([os.path.getsize(p) for p in paths]))
+        assert np.array_equal(readRadarRecord(paths[0]), recs[0])
         t0 = time.perf_counter()
         for p in paths[:24]:
             readRadarRecord(p)
         one = (time.perf_counter() - t0) / 24
-        t0 = time.perf_counter()
-        k = sum(1 for _ in prefetchRadarRecords(paths, workers))
-        dec_thr = time.perf_counter() - t0
-        assert k == n
-        with RecordDecodePool(workers) as pool:                                                       # (start-up of the processes: untimed)
-            for _ in pool.records(paths[:64]):                                                        # ... every worker has finished importing
+        with NativeRecordReader(w, ctx=ctx, hold=RING) as rd:
+            for _ in rd.records(paths[:64]):
                 pass
             t0 = time.perf_counter()
-            k = sum(1 for _ in pool.records(paths))
+            k = sum(1 for _ in rd.records(paths))
             dec = time.perf_counter() - t0
             assert k == n
-            stream_records(pool.records(paths[:12]), 12, poses[0], flags, ctx)                       # warm-up
+            stream_records(rd.records(paths[:12]), 12, poses[0], flags, ctx, records_pinned=True)       # warm-up
             t0 = time.perf_counter()
-            est, _ = stream_records(pool.records(paths), n, poses[0], flags, ctx)
+            est, _ = stream_records(rd.records(paths), n, poses[0], flags, ctx, records_pinned=True)
             dt = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        est_t, _ = stream_records(prefetchRadarRecords(paths, workers), n, poses[0], flags, ctx)     # the thread pool of the same size
-        dtt = time.perf_counter() - t0
-        assert est_t.tobytes() == est.tobytes()
+        with RecordDecodePool(w) as pool:                                                             # (start-up of the processes: untimed)
+            for _ in pool.records(paths[:64]):
+                pass
+            t0 = time.perf_counter()
+            est_p, _ = stream_records(pool.records(paths), n, poses[0], flags, ctx)
+            dtp = time.perf_counter() - t0
+        assert est_p.tobytes() == est.tobytes()
         t0 = time.perf_counter()
         est1, _ = stream_records(prefetchRadarRecords(paths, 1), n, poses[0], flags, ctx)            # the decode on the feeding thread (round 4)
         dt1 = time.perf_counter() - t0
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    w = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 2))
-    return est, est1, {"png_inclusive_pairs_per_s": round((n - 1) / dt, 2), "png_inclusive_pairs_per_s_thread_pool": round((n - 1) / dtt, 2),
+    return est, est1, {"png_inclusive_pairs_per_s": round((n - 1) / dt, 2), "png_inclusive_pairs_per_s_pillow_process_pool": round((n - 1) / dtp, 2),
                        "png_inclusive_pairs_per_s_one_decode_thread": round((n - 1) / dt1, 2),
-                       "png_decode_only_frames_per_s": round(n / dec, 1), "png_decode_only_frames_per_s_thread_pool": round(n / dec_thr, 1),
+                       "png_decode_only_frames_per_s": round(n / dec, 1),
                        "png_decode_ms_per_frame_one_thread": round(one * 1e3, 2),
-                       "png_decode_processes": w, "png_mean_file_bytes": int(size)}
+                       "png_decode_threads": w, "png_mean_file_bytes": int(size)}
 
 
 def run_stream(args):

@@ -57,6 +57,24 @@ int32_t roam_synchronize(roam_ctx *ctx);
 int32_t roam_host_alloc(roam_ctx *ctx, int64_t bytes, void **out);
 int32_t roam_host_free(roam_ctx *ctx, void *p);
 
+/* ---- f2: record ingest from PNG files (parseData.py:160-226: cv2.imread(path, IMREAD_GRAYSCALE) at :178; the reference decodes
+ * frame k inside its loop, RawROAMSystem.py:162-165).  Host code only - no device, no context.  The one format of the data set:
+ * 8-bit greyscale, non-interlaced; anything else (and a corrupt file) is ROAM_E_ARG.  The image is written row by row into out
+ * (out_stride bytes between rows, 0 = the image width; ROAM_E_CAPACITY when (rows - 1) * out_stride + cols > out_bytes) - typically
+ * a slot of a roam_host_alloc ring, so that a decoded record is uploaded from where it was decoded.  rows / cols may be NULL. */
+int32_t roam_png_decode_gray8(const uint8_t *png, int64_t png_bytes, uint8_t *out, int64_t out_bytes, int64_t out_stride,
+                              int32_t *rows, int32_t *cols);
+int32_t roam_png_decode_file(const char *path, uint8_t *out, int64_t out_bytes, int64_t out_stride, int32_t *rows, int32_t *cols);
+/* a pool of host threads decoding files ahead of the consumer.  submit() queues one file for one destination and returns at once; the
+ * caller names the job with a ticket of its choice (unique among the jobs in flight) and wait(ticket) blocks until THAT job is done and
+ * returns its status (tickets complete in any order; every submitted ticket must be waited for before its destination is reused).
+ * destroy() drops the jobs that have not started and joins the threads. */
+typedef struct roam_png_pool roam_png_pool;
+int32_t roam_png_pool_create(int32_t workers, roam_png_pool **out);
+int32_t roam_png_pool_submit(roam_png_pool *pool, const char *path, uint8_t *dst, int64_t dst_bytes, int64_t dst_stride, int64_t ticket);
+int32_t roam_png_pool_wait(roam_png_pool *pool, int64_t ticket, int32_t *rows, int32_t *cols);
+int32_t roam_png_pool_destroy(roam_png_pool *pool);
+
 /* ---- a2: getPointCloud.getPointCloudPolarInd (getPointCloud.py:11-54) ------------------
  * polar: rows x cols float32.  out: (cap,2) int32 rows [azimuthIdx, rangeIdx], azimuth-
  * major, range ascending.  *n_out = number of peaks found; if it exceeds cap the call

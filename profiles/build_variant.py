@@ -13,5 +13,5 @@ cmd = ["/opt/rocm/bin/hipcc"] + B.FLAGS + B.EXTRA.get(src, []) + extra + ["-c", 
 subprocess.run(cmd, check=True)
 objs = [obj if f == src else os.path.join(B.CSRC, f[:-4] + ".o") for f in B._sources()]
 out = os.path.join(ROOT, "variants", f"libroam_{name}.so")
-subprocess.run(["/opt/rocm/bin/hipcc", f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lz"], check=True)
 print(out)

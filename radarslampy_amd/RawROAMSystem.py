@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parseData import RecordDecodePool, getRadarImgPaths, prefetchRadarRecords
+from .parseData import NativeRecordReader, RecordDecodePool, getRadarImgPaths, prefetchRadarRecords
 from .trajectoryPlotting import Trajectory, computePosesRMSE, getGroundTruthTrajectory
 from .utils import radarImgPathToTimestamp
 
@@ -53,14 +53,17 @@ class RawROAMSystem:
             if initPose is None:
                 initPose = self.gtTraj.getPoseAtTimes(stamps[0])
         initPose = np.zeros(3) if initPose is None else np.asarray(initPose, np.float64)
-        # PNG inflate runs ahead of the loop on a pool of host processes (parseData.RecordDecodePool; a handful of frames: threads): the
-        # thread that feeds the pinned ring only copies decoded records
+        # PNG inflate + un-filter run ahead of the loop on the library's pool of host threads (parseData.NativeRecordReader ->
+        # roam_png_pool_*), straight into a ring of pinned slots the records are uploaded from: the feeding thread copies nothing
         paths = [self.imgPathArr[i] for i in frames]
-        if len(paths) >= 64 and self.decodeWorkers != 1:
-            with RecordDecodePool(self.decodeWorkers) as pool:
-                poses, log = stream_records(pool.records(paths), len(frames), initPose, self.paramFlags, self.ctx)
-        else:
-            poses, log = stream_records(prefetchRadarRecords(paths, self.decodeWorkers), len(frames), initPose, self.paramFlags, self.ctx)
+        ctx = self.ctx or _ffi.Context(int(os.environ.get("ROAM_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        try:
+            workers = self.decodeWorkers if self.decodeWorkers > 0 else default_decode_workers()
+            with NativeRecordReader(min(workers, max(1, len(paths))), ctx=ctx, hold=RING) as rd:
+                poses, log = stream_records(rd.records(paths), len(frames), initPose, self.paramFlags, ctx, records_pinned=True)
+        finally:
+            if self.ctx is None:
+                ctx.close()
         self.estTraj = Trajectory([stamps[0]], [initPose])
         self.estTraj.extend_absolute(stamps[1:], poses)
         for k, e in enumerate(log):
@@ -74,12 +77,21 @@ class RawROAMSystem:
         return computePosesRMSE(self.gtTraj.getPoseAtTimes(self.estTraj.timestamps), self.estTraj.poses)
 
 
+def default_decode_workers():
+    """host threads inflating PNGs for one sequence: half the cores this rank may count on, at most 32"""
+    cores = os.cpu_count() or 2
+    per_node = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    return max(1, min(32, cores // 2 // per_node))
+
+
 def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows=400, stride=3779, payload_off=11, clip=2025,
-                   synchronous=False, on_engine=None, after_step=None, before_close=None):
+                   synchronous=False, on_engine=None, after_step=None, before_close=None, records_pinned=False):
     """records: iterator of n_frames (rows, stride) u8 Oxford records of ONE sequence.  -> (poses (n_frames-1, 3), per-pair log).
     Frame 0 seeds the lane (features detected on the device); frame k is uploaded LOOKAHEAD frames before step k needs it.
     synchronous=True awaits every pose before the next frame is stepped (the latency of one pair instead of the pipeline's
     rate; same poses) and also returns the per-pair seconds from the step call to the pose on the host.
+    records_pinned: every record is a view of pinned memory that stays untouched for RING more frames (NativeRecordReader(hold=RING)):
+    it is uploaded from where it lies instead of through this function's staging ring.
     Hooks (the multi-GPU keyframe exchange of BASELINE config 5 lives in them): on_engine(eng) once after the engine exists,
     after_step(eng, k) after every enqueued step, before_close(eng) when all poses are in."""
     flags = dict(paramFlags or {})
@@ -90,7 +102,7 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
                  retrack_on_device=True, stage_events=False)
     if on_engine is not None:
         on_engine(eng)
-    pinned = ctx.host_alloc((RING, rows, stride))
+    pinned = None if records_pinned else ctx.host_alloc((RING, rows, stride))
     it = iter(records)
     uploaded = 0
 
@@ -100,8 +112,11 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
         if rec is None:
             return False
         slot = uploaded % RING
-        pinned[slot] = rec
-        eng.upload_scans_async(slot, pinned[slot], n=1)
+        if records_pinned:
+            eng.upload_scans_async(slot, rec, n=1)
+        else:
+            pinned[slot] = rec
+            eng.upload_scans_async(slot, pinned[slot], n=1)
         uploaded += 1
         return True
 
@@ -141,7 +156,8 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
         if before_close is not None:
             before_close(eng)
     finally:
-        ctx.host_free(pinned)
+        if pinned is not None:
+            ctx.host_free(pinned)
         eng.close()
         if own:
             ctx.close()

@@ -52,6 +52,12 @@ _SIGS = {
     "roam_synchronize": (C.c_int32, [_vp]),
     "roam_host_alloc": (C.c_int32, [_vp, C.c_int64, _P(_vp)]),
     "roam_host_free": (C.c_int32, [_vp, _vp]),
+    "roam_png_decode_gray8": (C.c_int32, [_vp, C.c_int64, _vp, C.c_int64, C.c_int64, _P(C.c_int32), _P(C.c_int32)]),
+    "roam_png_decode_file": (C.c_int32, [C.c_char_p, _vp, C.c_int64, C.c_int64, _P(C.c_int32), _P(C.c_int32)]),
+    "roam_png_pool_create": (C.c_int32, [C.c_int32, _P(_vp)]),
+    "roam_png_pool_submit": (C.c_int32, [_vp, C.c_char_p, _vp, C.c_int64, C.c_int64, C.c_int64]),
+    "roam_png_pool_wait": (C.c_int32, [_vp, C.c_int64, _P(C.c_int32), _P(C.c_int32)]),
+    "roam_png_pool_destroy": (C.c_int32, [_vp]),
     "roam_peaks_polar_f32": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
     "roam_peaks_record_u8": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_int64, _P(C.c_int64)]),
     "roam_polar_to_cart_f32": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp, _vp]),

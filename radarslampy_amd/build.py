@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if r.returncode != 0:
                 raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lz"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)

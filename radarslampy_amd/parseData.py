@@ -1,5 +1,7 @@
 """Oxford record decode + polar->Cartesian warp with the reference's names
 (reference parseData.py:9-53,100-135).  The warp runs on the MI355X (warp.hip)."""
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -48,8 +50,21 @@ def getRadarImgPaths(dataPath: str, timestampPath: str):
 
 
 def readRadarRecord(imgPath: str) -> np.ndarray:
-    """(400, 3779) u8 Oxford record from a PNG (the reference uses cv2.imread(..., IMREAD_GRAYSCALE),
-    parseData.py:178; Pillow decodes the same 8-bit greyscale PNG).  PNG inflate is host work (§8f-f2)."""
+    """(400, 3779) u8 Oxford record from a PNG (the reference uses cv2.imread(..., IMREAD_GRAYSCALE), parseData.py:178).  The data
+    set's format - 8-bit greyscale, non-interlaced - is decoded by the library (roam_png_decode_file: zlib inflate + un-filter, host
+    code); any other PNG goes through Pillow's conversion to 8-bit grey, as cv2 would convert it.  PNG inflate is host work (8f-f2)."""
+    import ctypes as C
+    from . import _ffi
+    if not os.path.exists(imgPath):
+        raise FileNotFoundError(imgPath)
+    lib = _ffi.load_library()
+    rows, cols = C.c_int32(0), C.c_int32(0)
+    rc = lib.roam_png_decode_file(os.fsencode(imgPath), None, 0, 0, C.byref(rows), C.byref(cols))     # header only: the size
+    if rc == _ffi.ROAM_E_CAPACITY and rows.value > 0 and cols.value > 0:
+        out = np.empty((rows.value, cols.value), np.uint8)
+        rc = lib.roam_png_decode_file(os.fsencode(imgPath), out.ctypes.data_as(C.c_void_p), out.size, 0, None, None)
+        if rc == _ffi.ROAM_OK:
+            return out
     from PIL import Image
     return np.array(Image.open(imgPath).convert("L"), dtype=np.uint8)
 
@@ -80,6 +95,81 @@ def prefetchRadarRecords(imgPaths, workers: int = 0, depth: int = 0):
             yield pending.popleft().result()
     finally:
         pool.shutdown(wait=True, cancel_futures=True)
+
+
+class NativeRecordReader:
+    """PNG files -> Oxford records, decoded by the library's pool of host THREADS (roam_png_pool_*: zlib inflate + PNG un-filter in C,
+    8f-f2) straight into the slots of a ring - pinned memory (roam_host_alloc) when a Context is given, so that a record is uploaded
+    from where it was decoded: no Pillow, no GIL, no copy between processes.  records() yields the frames IN ORDER as views of their
+    slots; the view of frame j stays untouched until the consumer asks for frame j + hold + 1 (an asynchronous upload from the slot has
+    `hold` frames to finish).  workers = 0: min(32, cores / 2); depth (slots, 1.5 MB each) = 0: hold + 2 x workers.  Context manager, or close()."""
+
+    def __init__(self, workers: int = 0, depth: int = 0, rec_shape=(400, 3779), ctx=None, hold: int = 1):
+        import ctypes as C
+        from . import _ffi
+        self._C, self._ffi = C, _ffi
+        self.lib = _ffi.load_library()
+        self.workers = workers if workers > 0 else max(1, min(32, (os.cpu_count() or 2) // 2))
+        self.hold = max(1, int(hold))
+        self.depth = depth if depth > 0 else self.hold + 2 * self.workers
+        if self.depth <= self.hold:
+            raise ValueError("depth must exceed hold")
+        self.rec_shape = tuple(int(v) for v in rec_shape)
+        self.rec_bytes = int(np.prod(self.rec_shape))
+        self.ctx = ctx
+        self.pinned = ctx is not None
+        self.ring = ctx.host_alloc((self.depth,) + self.rec_shape) if ctx is not None else np.empty((self.depth,) + self.rec_shape, np.uint8)
+        h = C.c_void_p()
+        rc = self.lib.roam_png_pool_create(self.workers, C.byref(h))
+        if rc != _ffi.ROAM_OK:
+            raise _ffi.RoamError(rc, "roam_png_pool_create")
+        self._pool = h
+        self._ticket = 0
+
+    def records(self, imgPaths):
+        C = self._C
+        paths = [os.fsencode(p) for p in imgPaths]
+        n = len(paths)
+        base, nxt, want = self._ticket, 0, 0
+        self._ticket += n
+        rows, cols = C.c_int32(0), C.c_int32(0)
+        try:
+            while want < n:
+                # frame i lives in slot i % depth: it may be submitted once frame i - depth is `hold` yields behind the consumer
+                while nxt < n and nxt < want + self.depth - self.hold:
+                    slot = self.ring[nxt % self.depth]
+                    rc = self.lib.roam_png_pool_submit(self._pool, paths[nxt], slot.ctypes.data_as(C.c_void_p), self.rec_bytes, self.rec_shape[1], base + nxt)
+                    if rc != self._ffi.ROAM_OK:
+                        raise self._ffi.RoamError(rc, "roam_png_pool_submit")
+                    nxt += 1
+                rc = self.lib.roam_png_pool_wait(self._pool, base + want, C.byref(rows), C.byref(cols))
+                want += 1
+                if rc != self._ffi.ROAM_OK:
+                    p = os.fsdecode(paths[want - 1])
+                    if not os.path.exists(p):
+                        raise FileNotFoundError(p)
+                    raise RuntimeError(f"{p}: not an 8-bit greyscale PNG of at most {self.rec_shape} (status {rc}, {rows.value} x {cols.value})")
+                if (rows.value, cols.value) == self.rec_shape:
+                    yield self.ring[(want - 1) % self.depth]
+                else:                                           # a smaller image: the rows lie rec_shape[1] bytes apart in the slot
+                    yield self.ring[(want - 1) % self.depth][:rows.value, :cols.value]
+        finally:
+            for i in range(want, nxt):                          # nothing of this iteration is left in flight when it ends, however it ends
+                self.lib.roam_png_pool_wait(self._pool, base + i, None, None)
+
+    def close(self):
+        if self._pool is not None:
+            self.lib.roam_png_pool_destroy(self._pool)
+            self._pool = None
+            if self.ctx is not None:
+                self.ctx.host_free(self.ring)
+            self.ring = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def _decode_worker(shm_name, rec_bytes, tasks, done):
