@@ -1,13 +1,17 @@
 // f2: native PNG decode of Oxford radar records, host code only (no device work in this file).
 //
 // Replaces cv2.imread(path, cv2.IMREAD_GRAYSCALE) of the reference's loader (parseData.py:160-226, the read at :178;
-// RawROAMSystem.py:162-165) for the one format the data set uses: 8-bit greyscale, non-interlaced.  zlib inflates the IDAT stream one
-// scanline at a time into a (width + 1)-byte line buffer and the PNG filter (None / Sub / Up / Average / Paeth, one byte per pixel) is
-// undone straight into the caller's destination rows - a slot of the pinned upload ring (roam_host_alloc): no intermediate image, no
-// Python, no GIL, no copy between processes.  Any other colour type, bit depth or interlacing is refused with ROAM_E_ARG.
+// RawROAMSystem.py:162-165) for the one format the data set uses: 8-bit greyscale, non-interlaced.  The IDAT stream is inflated by
+// csrc/fastinflate.h (whole stream in, whole filtered image out; Adler-32 checked) and the PNG filter (None / Sub / Up / Average / Paeth,
+// one byte per pixel; the data set's files are Sub on every line: a byte prefix sum, SSE2) is undone while the lines move to the
+// caller's destination rows - a slot of the pinned upload ring (roam_host_alloc): no Python, no GIL, no copy between processes.  Whatever
+// the fast inflate refuses is inflated again by zlib, a group of scanlines at a time, which owns the verdict on a damaged file.
+// Any other colour type, bit depth or interlacing is refused with ROAM_E_ARG.
 // A pool of host threads (roam_png_pool_*) decodes files ahead of the consumer; tickets complete in any order and are awaited one by one.
 #include "roam_internal.h"
+#include "fastinflate.h"
 #include <zlib.h>
+#include <emmintrin.h>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -105,7 +109,87 @@ void unfilter_paeth_rows(uint8_t *const *rows, const uint8_t *__restrict__ prev,
     }
 }
 
-struct Scratch { std::vector<uint8_t> file, line; };
+// Sub on one line, source and destination apart: dst[i] = src[i] + dst[i - 1] - a byte prefix sum, 16 bytes a step (log-step shifts and adds
+// inside the register, the last byte carried to the next step)
+void unfilter_sub_copy(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int n)
+{
+    int i = 0;
+    __m128i carry = _mm_setzero_si128();
+    for (; i + 16 <= n; i += 16) {
+        __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+        x = _mm_add_epi8(x, _mm_slli_si128(x, 1));
+        x = _mm_add_epi8(x, _mm_slli_si128(x, 2));
+        x = _mm_add_epi8(x, _mm_slli_si128(x, 4));
+        x = _mm_add_epi8(x, _mm_slli_si128(x, 8));
+        x = _mm_add_epi8(x, carry);
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(dst + i), x);
+        carry = _mm_set1_epi8((char)(_mm_extract_epi16(x, 7) >> 8));
+    }
+    int a = i ? dst[i - 1] : 0;
+    for (; i < n; i++) { a = (uint8_t)(src[i] + a); dst[i] = (uint8_t)a; }
+}
+
+struct Scratch { std::vector<uint8_t> file, line, z, raw; fastinflate::Tables tab; };
+
+// undo the filters of lines [y0, y0 + nl) whose filtered bytes (filter type first) lie LP apart from `lines`, writing the image rows of `out`.
+// false: a filter type that does not exist
+bool unfilter_lines(const uint8_t *lines, size_t LP, uint32_t y0, uint32_t nl, uint32_t W, uint8_t *out, int64_t out_stride)
+{
+    for (uint32_t i = 0; i < nl; i++)
+        if (lines[LP * i] > 4) return false;
+    uint32_t i = 0;
+    while (i < nl) {
+        const int ft = lines[LP * i];
+        uint8_t *dst = out + (int64_t)(y0 + i) * out_stride;
+        if (ft == 1) { unfilter_sub_copy(lines + LP * i + 1, dst, (int)W); i++; continue; }
+        uint32_t run = 1;
+        if (ft == 4 && y0 + i > 0)
+            while (i + run < nl && run < 4 && lines[LP * (i + run)] == 4) run++;
+        for (uint32_t k = 0; k < run; k++) memcpy(dst + (int64_t)k * out_stride, lines + LP * (i + k) + 1, W);
+        if (run >= 2) {
+            uint8_t *rw[4];
+            for (uint32_t k = 0; k < run; k++) rw[k] = dst + (int64_t)k * out_stride;
+            if (run == 4) unfilter_paeth_rows<4>(rw, dst - out_stride, (int)W);
+            else if (run == 3) unfilter_paeth_rows<3>(rw, dst - out_stride, (int)W);
+            else unfilter_paeth_rows<2>(rw, dst - out_stride, (int)W);
+        } else
+            unfilter_row(ft, dst, (y0 + i) ? dst - out_stride : nullptr, (int)W);
+        i += run;
+    }
+    return true;
+}
+
+// the fast path: every IDAT payload gathered into one buffer, inflated in one go, Adler-32 compared, filters undone.  false: use zlib
+bool decode_fast(const uint8_t *png, int64_t nbytes, int64_t pos, uint32_t W, uint32_t H, uint8_t *out, int64_t out_stride, Scratch &sc)
+{
+    size_t zn = 0;
+    for (int64_t p = pos; p + 12 <= nbytes;) {
+        const uint32_t len = be32(png + p);
+        if (p + 12 + (int64_t)len > nbytes) return false;
+        if (memcmp(png + p + 4, "IDAT", 4) == 0) zn += len;
+        else if (memcmp(png + p + 4, "IEND", 4) == 0) break;
+        p += 12 + (int64_t)len;
+    }
+    if (zn < 2 + 4) return false;
+    sc.z.resize(zn + 64);
+    size_t at = 0;
+    for (int64_t p = pos; p + 12 <= nbytes;) {
+        const uint32_t len = be32(png + p);
+        if (memcmp(png + p + 4, "IDAT", 4) == 0) { memcpy(sc.z.data() + at, png + p + 8, len); at += len; }
+        else if (memcmp(png + p + 4, "IEND", 4) == 0) break;
+        p += 12 + (int64_t)len;
+    }
+    memset(sc.z.data() + zn, 0, 64);
+    const uint8_t *z = sc.z.data();
+    if ((z[0] & 15) != 8 || (z[0] >> 4) > 7 || ((z[0] << 8) | z[1]) % 31 != 0 || (z[1] & 0x20)) return false;     // deflate, window <= 32 KB, no dictionary
+    const size_t LP = (size_t)W + 1, rawn = LP * H;
+    sc.raw.resize(rawn + 258 + 64);
+    size_t used = 0;
+    if (!fastinflate::inflate(z + 2, zn - 2, sc.raw.data(), rawn, &used, sc.tab)) return false;
+    if (2 + used + 4 > zn) return false;
+    if (be32(z + 2 + used) != (uint32_t)adler32(adler32(0L, Z_NULL, 0), sc.raw.data(), (uInt)rawn)) return false;
+    return unfilter_lines(sc.raw.data(), LP, 0, H, W, out, out_stride);
+}
 
 int32_t decode_gray8(const uint8_t *png, int64_t nbytes, uint8_t *out, int64_t out_bytes, int64_t out_stride, int32_t *rows, int32_t *cols,
                      Scratch &sc)
@@ -123,6 +207,8 @@ int32_t decode_gray8(const uint8_t *png, int64_t nbytes, uint8_t *out, int64_t o
     if (out_stride == 0) out_stride = W;
     if (!out || out_stride < (int64_t)W || (int64_t)(H - 1) * out_stride + W > out_bytes) return ROAM_E_CAPACITY;
     pos += 12 + 13;
+    if (decode_fast(png, nbytes, pos, W, H, out, out_stride, sc)) return ROAM_OK;
+    // ---- zlib, a group of scanlines at a time (what the fast path refused: it may be a damaged file, it may be a stream shape it does not take)
     constexpr uint32_t G = 8;                                       // scanlines inflated per call
     const size_t LP = (size_t)W + 1;
     sc.line.resize(LP * G);
@@ -134,29 +220,8 @@ int32_t decode_gray8(const uint8_t *png, int64_t nbytes, uint8_t *out, int64_t o
     zs.next_out = sc.line.data();
     zs.avail_out = (uInt)(LP * want);
     bool ended = false, bad = false;
-    // the group's lines: filter byte checked, bytes moved to their destination rows, filters undone (runs of Paeth lines four at a time)
     auto flush_lines = [&](uint32_t nl) {
-        for (uint32_t i = 0; i < nl; i++) {
-            if (sc.line[LP * i] > 4) { bad = true; return; }
-            memcpy(out + (int64_t)(y + i) * out_stride, sc.line.data() + LP * i + 1, W);
-        }
-        uint32_t i = 0;
-        while (i < nl) {
-            const int ft = sc.line[LP * i];
-            uint8_t *dst = out + (int64_t)(y + i) * out_stride;
-            uint32_t run = 1;
-            if (ft == 4 && y + i > 0)
-                while (i + run < nl && run < 4 && sc.line[LP * (i + run)] == 4) run++;
-            if (run >= 2) {
-                uint8_t *rw[4];
-                for (uint32_t k = 0; k < run; k++) rw[k] = dst + (int64_t)k * out_stride;
-                if (run == 4) unfilter_paeth_rows<4>(rw, dst - out_stride, (int)W);
-                else if (run == 3) unfilter_paeth_rows<3>(rw, dst - out_stride, (int)W);
-                else unfilter_paeth_rows<2>(rw, dst - out_stride, (int)W);
-            } else
-                unfilter_row(ft, dst, (y + i) ? dst - out_stride : nullptr, (int)W);
-            i += run;
-        }
+        if (!unfilter_lines(sc.line.data(), LP, y, nl, W, out, out_stride)) { bad = true; return; }
         y += nl;
     };
     while (pos + 12 <= nbytes && !bad) {
@@ -242,14 +307,14 @@ extern "C" {
 int32_t roam_png_decode_gray8(const uint8_t *png, int64_t png_bytes, uint8_t *out, int64_t out_bytes, int64_t out_stride,
                               int32_t *rows, int32_t *cols)
 {
-    Scratch sc;
+    static thread_local Scratch sc;                                 // (buffers of the calling thread, kept from call to call)
     return decode_gray8(png, png_bytes, out, out_bytes, out_stride, rows, cols, sc);
 }
 
 int32_t roam_png_decode_file(const char *path, uint8_t *out, int64_t out_bytes, int64_t out_stride, int32_t *rows, int32_t *cols)
 {
     if (!path) return ROAM_E_ARG;
-    Scratch sc;
+    static thread_local Scratch sc;
     return decode_file(path, out, out_bytes, out_stride, rows, cols, sc);
 }
 

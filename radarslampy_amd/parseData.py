@@ -1,6 +1,7 @@
 """Oxford record decode + polar->Cartesian warp with the reference's names
 (reference parseData.py:9-53,100-135).  The warp runs on the MI355X (warp.hip)."""
 import os
+import time
 
 import numpy as np
 
@@ -125,6 +126,7 @@ class NativeRecordReader:
             raise _ffi.RoamError(rc, "roam_png_pool_create")
         self._pool = h
         self._ticket = 0
+        self.wait_s = 0.0                                           # seconds the consumer has spent blocked on a frame that was not ready
 
     def records(self, imgPaths):
         C = self._C
@@ -142,7 +144,9 @@ class NativeRecordReader:
                     if rc != self._ffi.ROAM_OK:
                         raise self._ffi.RoamError(rc, "roam_png_pool_submit")
                     nxt += 1
+                t0 = time.perf_counter()
                 rc = self.lib.roam_png_pool_wait(self._pool, base + want, C.byref(rows), C.byref(cols))
+                self.wait_s += time.perf_counter() - t0
                 want += 1
                 if rc != self._ffi.ROAM_OK:
                     p = os.fsdecode(paths[want - 1])

@@ -199,3 +199,35 @@ def stream_jobs(world: StreamWorld, poses, distortion: bool = False, scintillati
             vel = np.array([d[0, 2], d[1, 2], np.arctan2(d[1, 0], d[0, 0])]) / 0.25
         jobs.append((world.seed, world.per_tile, world.mover_fraction, np.asarray(pose, float), t, vel, scintillation))
     return jobs
+
+
+def png_bytes_gray8(img: np.ndarray, filter_type: int = 1, level: int = 1, rle: bool = True, idat_bytes: int = 8192) -> bytes:
+    """an 8-bit greyscale PNG of `img` the way the Oxford Radar RobotCar files are written (checked on the reference's data/tiny scans: Sub
+    filter on every scanline, zlib stream header 78 01, IDAT chunks of 8 192 bytes - OpenCV's cv2.imwrite defaults: compression level 1,
+    Z_RLE).  filter_type 0 (None) / 1 (Sub) / 2 (Up) for every line; used by bench.py --png and the tests, no part of the product path."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(img, np.uint8)
+    h, w = a.shape
+    if filter_type == 0:
+        body = a
+    elif filter_type == 1:
+        body = a.copy()
+        body[:, 1:] -= a[:, :-1]
+    elif filter_type == 2:
+        body = a.copy()
+        body[1:] -= a[:-1]
+    else:
+        raise ValueError("filter_type 0, 1 or 2")
+    raw = np.empty((h, w + 1), np.uint8)
+    raw[:, 0] = filter_type
+    raw[:, 1:] = body
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, zlib.Z_RLE if rle else zlib.Z_DEFAULT_STRATEGY)
+    z = co.compress(raw.tobytes()) + co.flush()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+    for i in range(0, len(z), idat_bytes):
+        out += chunk(b"IDAT", z[i:i + idat_bytes])
+    return out + chunk(b"IEND", b"")

@@ -18,7 +18,7 @@ def _chunk(tag, data):
     return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
 
 
-def write_png(img, filters, idat_split=0, depth=8, ctype=0, interlace=0, level=6):
+def write_png(img, filters, idat_split=0, depth=8, ctype=0, interlace=0, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
     """8-bit greyscale PNG of `img` with filter type filters[y % len] on scanline y (None 0, Sub 1, Up 2, Average 3, Paeth 4)"""
     h, w = img.shape
     a = img.astype(np.int32)
@@ -43,7 +43,8 @@ def write_png(img, filters, idat_split=0, depth=8, ctype=0, interlace=0, level=6
             pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, ul))
         raw.append(ft)
         raw += ((cur - pred) & 255).astype(np.uint8).tobytes()
-    z = zlib.compress(bytes(raw), level)
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+    z = co.compress(bytes(raw)) + co.flush()
     parts = [z] if idat_split <= 0 else [z[i:i + idat_split] for i in range(0, len(z), idat_split)]
     out = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
     out += _chunk(b"tEXt", b"Comment\x00made by the test")          # an ancillary chunk before the data
@@ -113,6 +114,29 @@ def test_random_images_all_filters():
         assert rc == _ffi.ROAM_OK and np.array_equal(got, img), (h, w, filt)
 
 
+def test_every_deflate_block_shape(tiny_payloads):
+    """the library's own inflate (csrc/fastinflate.h) on stored blocks, the fixed code, dynamic codes of every strategy, long matches at
+    distance 1, short distances 2..7, distances up to the window - always against Pillow (zlib)"""
+    rng = np.random.default_rng(11)
+    real = np.ascontiguousarray(tiny_payloads[5][:120, :1500])
+    imgs = {"real": real, "zeros": np.zeros((200, 3000), np.uint8), "noise": rng.integers(0, 256, (64, 1000), dtype=np.uint8),
+            "period3": np.tile(np.array([7, 200, 31], np.uint8), (90, 333)), "period5": np.tile(np.arange(5, dtype=np.uint8) * 50, (70, 400)),
+            "far": np.vstack([rng.integers(0, 256, (8, 3900), dtype=np.uint8)] * 6),          # matches 31 KB back
+            "ramp": (np.arange(300 * 700, dtype=np.int64).reshape(300, 700) % 251).astype(np.uint8)}
+    for name, img in imgs.items():
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_RLE), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)):
+            for filt in ((1,), (0,), (4, 1, 2)):
+                png = write_png(img, filt, idat_split=8192, level=level, strategy=strategy)
+                rc, got = decode(png)
+                assert rc == _ffi.ROAM_OK and np.array_equal(got, img), (name, level, strategy, filt)
+    from radarslampy_amd.synth import png_bytes_gray8                 # the writer bench.py uses: the data set's format
+    png = png_bytes_gray8(real)
+    assert png[8 + 25 + 8:8 + 25 + 10] == b"\x78\x01"
+    rc, got = decode(png)
+    assert rc == _ffi.ROAM_OK and np.array_equal(got, real) and np.array_equal(pillow(png), real)
+
+
 def test_refused_formats_and_corrupt_files(tiny_payloads):
     img = np.ascontiguousarray(tiny_payloads[0][:16, :64])
     ok = write_png(img, (4,))
@@ -122,10 +146,15 @@ def test_refused_formats_and_corrupt_files(tiny_payloads):
     assert decode(write_png(img, (4,), interlace=1))[0] == _ffi.ROAM_E_ARG      # Adam7
     assert decode(b"not a png at all" * 4)[0] == _ffi.ROAM_E_ARG
     assert decode(ok[:len(ok) // 2])[0] == _ffi.ROAM_E_ARG                      # truncated
-    bad = bytearray(ok)
-    bad[len(bad) // 2] ^= 0x55                                                  # a flipped byte inside the zlib stream
-    rc, got = decode(bytes(bad))
-    assert rc == _ffi.ROAM_E_ARG or not np.array_equal(got, img)                # (zlib's Adler-32 catches what still inflates)
+    big = np.ascontiguousarray(tiny_payloads[0][:64, :900])
+    okb = write_png(big, (1,), level=1, strategy=zlib.Z_RLE)
+    rng = np.random.default_rng(3)
+    for _ in range(40):                                                         # a flipped byte anywhere in the zlib stream: refused (Adler-32 at the latest),
+        bad = bytearray(okb)                                                    # never a wrong image, never a crash
+        k = int(rng.integers(8 + 25 + 8 + 27, len(bad) - 16))
+        bad[k] ^= int(rng.integers(1, 256))
+        rc, got = decode(bytes(bad))
+        assert rc == _ffi.ROAM_E_ARG or np.array_equal(got, big)
     assert decode(write_png(img, (7,)))[0] == _ffi.ROAM_E_ARG                   # no such filter
     import ctypes as C
     lib = _ffi.load_library()
