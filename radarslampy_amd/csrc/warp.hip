@@ -229,8 +229,9 @@ template <int U, bool CHK, bool RAWK = false>
 __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t lane_stride,
                                          const int32_t *__restrict__ lane_index, int l, int64_t row_stride, int rows,
                                          int cols, int mnx, int mny, int bw, int bp, int bh, int elems, int wvs, int lane,
-                                         float *__restrict__ bq)
+                                         float *__restrict__ bq, int pp = 0)
 {
+    // pp != 0: the swizzled layout of the kernel below (WG_SWZ) - sample c of a row at float c + (c >> 5), pitch pp
     int64_t so[U];
 #pragma unroll
     for (int u = 0; u < U; u++) so[u] = (lane_index ? (int64_t)lane_index[l + u] : (int64_t)(l + u)) * lane_stride;
@@ -243,7 +244,7 @@ __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t
             const int c = min(cb + c4, bp - 4);           // clamped lanes rewrite the last column group
             const int x0 = mnx + c;                       // first range bin of this lane's dword
             const uint8_t *srow = sp + (__mul24(r, (int)row_stride) + x0);       // rows * stride < 2^31 (launcher requirement)
-            float *drow = bq + (k * bp + c);
+            float *drow = pp ? bq + (k * pp + c + (c >> 5)) : bq + (k * bp + c);
             uint32_t raw[U];
 #pragma unroll
             for (int u = 0; u < U; u++) raw[u] = *reinterpret_cast<const u32_a1 *>(srow + so[u]);
@@ -257,7 +258,12 @@ __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t
                 v.y = (!CHK || x0 + 1 < cols) ? (RAWK ? (float)((raw[u] >> 8) & 255u) : code_to_f32((raw[u] >> 8) & 255u)) : 0.f;
                 v.z = (!CHK || x0 + 2 < cols) ? (RAWK ? (float)((raw[u] >> 16) & 255u) : code_to_f32((raw[u] >> 16) & 255u)) : 0.f;
                 v.w = (!CHK || x0 + 3 < cols) ? (RAWK ? (float)(raw[u] >> 24) : code_to_f32(raw[u] >> 24)) : 0.f;
-                *reinterpret_cast<float4 *>(drow + u * elems) = v;
+                if (pp) {                                 // (4-byte aligned only: four dword stores; the slot before a 32-sample block repeats its first sample)
+                    float *d = drow + u * elems;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                    if ((c & 31) == 0 && c > 0) d[-1] = v.x;
+                } else
+                    *reinterpret_cast<float4 *>(drow + u * elems) = v;
             }
         }
     }
@@ -353,12 +359,22 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
     if (WG_BP_MODE == 1 && (bp_ & 4) == 0) bp_ += 4;  // (experiment: an odd multiple of four floats - rows k, k + 1, .. start in different banks)
     if (WG_BP_MODE == 2) { while ((bp_ & 31) != 4) bp_ += 4; }
     const int bp = bp_;
-    const int elems = bp * bh;
+    // WG_SWZ (experiment, round 6; NOT the default): adjacent pixels of a tile whose rows run along the range axis sit two samples apart, so
+    // the 32 lanes of an LDS access group meet 16 banks.  With one spare float after every 32 samples of a box row the second half of
+    // such a group lands on the other parity; the spare slot repeats the sample that follows it, so that the pair (c, c + 1) stays two
+    // neighbouring floats.  Bit-identical, and no better: over all tiles the tap reads average 2.05 LDS cycles per 32-lane dword access
+    // with either layout (a model of the bank mapping over the real sampling map: profiles/r06_warp_experiments.txt) - the footprint of
+    // a tile is a slanted patch, not a stride - and the PMC conflict count rose (2.42e8 -> 2.73e8 with the four dword stores of the fill).
+#ifndef WG_SWZ
+#define WG_SWZ 0
+#endif
+    const int pp = WG_SWZ ? bp + (bp >> 5) + 1 : bp;   // physical pitch of a box row
+    const int elems = pp * bh;
     const bool use_box = any && (elems <= WG_BOX_ELEMS);
     int off0[4], off1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (use_box) { off0[j] = (iyv[j] - mny) * bp + (ixv[j] - mnx); off1[j] = off0[j] + bp; }
+        if (use_box) { const int cc = ixv[j] - mnx; off0[j] = (iyv[j] - mny) * pp + cc + (WG_SWZ ? (cc >> 5) : 0); off1[j] = off0[j] + pp; }
         else {
             int r0 = iyv[j] - 1, r1 = iyv[j];
             if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
@@ -455,8 +471,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             const int rem = nq - qb;
             const uint8_t *sp = pool + payload_off;
             float *bq = box + qb * elems;
-#define WG_FILL(U_) { if (chk) box_fill<U_, true, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); \
-                      else box_fill<U_, false, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += U_; }
+#define WG_FILL(U_) { if (chk) box_fill<U_, true, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); \
+                      else box_fill<U_, false, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); qb += U_; }
             if (rem >= 8 && WG_FILL_U >= 8) WG_FILL(8)
             else if (rem >= 4 && WG_FILL_U >= 4) WG_FILL(4)
             else if (rem >= 2 && WG_FILL_U >= 2) WG_FILL(2)
@@ -524,8 +540,8 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             const int rem = nq - qb;
             const uint8_t *sp = pool + payload_off;
             float *bq = box + qb * elems;
-#define WG_FILL(U_) { if (chk) box_fill<U_, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); \
-                      else box_fill<U_, false>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq); qb += U_; }
+#define WG_FILL(U_) { if (chk) box_fill<U_, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); \
+                      else box_fill<U_, false>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); qb += U_; }
             if (rem >= 8 && WG_FILL_U >= 8) WG_FILL(8)
             else if (rem >= 4 && WG_FILL_U >= 4) WG_FILL(4)
             else if (rem >= 2 && WG_FILL_U >= 2) WG_FILL(2)
