@@ -381,6 +381,13 @@ int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane);
  * ring of n keyframes in this rank's HBM (the oldest is overwritten); the sending rank included, so all ranks hold the same
  * global map.  count: keyframes received so far / resident now; get: index 0 = the oldest resident one. */
 int32_t roam_remote_map_reserve(roam_ctx *ctx, int32_t keyframes);
+/* test / debug: the receive half of roam_keyframe_exchange on ONE GPU, without a communicator.  recv (host) = `world` records as the
+ * all-gather of a `world`-rank job leaves them in a rank's receive buffer (record r = rank r's; *rec_bytes apart; roam_keyframe_hdr at
+ * 0, n_features x 2 float64 at *locals_off, n_peaks x 2 int32 at *peaks_off; n_features < 0 = "no keyframe in this step").  The records
+ * go through the kernel the exchange runs (Map.addKeyframe in rank order, Mapping.py:176-180) into this context's remote map: read it
+ * back with roam_remote_map_count / _get.  recv == NULL: only the layout is returned.  Needs roam_remote_map_reserve(>= world). */
+int32_t roam_debug_keyframe_append(roam_ctx *ctx, const uint8_t *recv, int32_t world, int64_t *rec_bytes, int32_t *locals_off,
+                                   int32_t *peaks_off, int32_t *max_peaks);
 int32_t roam_remote_map_count(roam_ctx *ctx, int64_t *received, int32_t *resident);
 int32_t roam_remote_map_get(roam_ctx *ctx, int32_t index, roam_keyframe_hdr *hdr_out, int32_t *root_out, double *locals_xy,
                             int32_t cap_pts, int32_t *peaks, int64_t peaks_cap);

@@ -51,7 +51,10 @@ RADAR_SCAN_FREQUENCY = 4             # motionDistortion.py:36
 
 
 def build(force: bool = False) -> str:
-    """Compile oracle/c/*.c into oracle/_build/liboracle.so (gcc only, a few seconds)."""
+    """Compile oracle/c/*.c into oracle/_build/liboracle.so (gcc only, a few seconds).  ORACLE_LIB: a library built elsewhere - the
+    sanitizer build of profiles/asan_cpu.sh - is used as it is."""
+    if os.environ.get("ORACLE_LIB"):
+        return os.environ["ORACLE_LIB"]
     srcs = [os.path.join(_HERE, "c", s) for s in _SRCS if os.path.exists(os.path.join(_HERE, "c", s))]
     if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return _LIB

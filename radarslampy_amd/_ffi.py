@@ -115,6 +115,7 @@ _SIGS = {
     "roam_keyframe_exchange": (C.c_int32, [_vp, C.c_int32]),
     "roam_remote_map_reserve": (C.c_int32, [_vp, C.c_int32]),
     "roam_remote_map_count": (C.c_int32, [_vp, _P(C.c_int64), _P(C.c_int32)]),
+    "roam_debug_keyframe_append": (C.c_int32, [_vp, _vp, C.c_int32, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "roam_remote_map_get": (C.c_int32, [_vp, C.c_int32, _P(KeyframeHdr), _P(C.c_int32), _vp, C.c_int32, _vp, C.c_int64]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
@@ -129,7 +130,10 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise RoamError(ROAM_E_NODEVICE, f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'`")
         lib = C.CDLL(LIB_PATH)
+        partial = bool(os.environ.get("ROAM_LIB_PARTIAL"))      # a host-only build (profiles/asan_cpu.sh): the symbols it has
         for name, (res, args) in _SIGS.items():
+            if partial and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
         _lib = lib

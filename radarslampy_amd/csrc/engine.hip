@@ -96,6 +96,7 @@ struct Engine {
     uint8_t *kfx_send = nullptr, *kfx_recv = nullptr;
     size_t kfx_rec = 0;                             // bytes of one record
     int kfx_peaks = 0;                              // peaks carried per record
+    int kfx_world = 0;                              // ranks the receive buffer was sized for
     int64_t *rmap_n_dev = nullptr;                  // keyframes appended by the exchange (device-side count)
     int32_t *rmap_root_dev = nullptr;               // their sending ranks, per slot
     int64_t kfx_calls = 0;
@@ -968,12 +969,13 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
         if (rc != ROAM_OK) return rc;
     }
     if (e->rmap_cap > 0) {
+        // (refused BEFORE anything is written: the exchange owns the ring slots and their count once it has run)
+        if (e->kfx_calls) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
         // Map.addKeyframe on this rank: the payload stays in HBM (device-to-device), header + features, then the peaks
         const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
         uint8_t *dst = e->rmap + (size_t)(e->rmap_n % e->rmap_cap) * slot_bytes;
         HIP_TRY(ctx, hipMemcpyAsync(dst, e->kfb, KFB_HDR + sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToDevice, st));
         if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(dst + KFB_PEAKS_OFF, e->kfb + KFB_PEAKS_OFF, (size_t)P * 8, hipMemcpyDeviceToDevice, st));
-        if (e->kfx_calls) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
         e->rmap_root[e->rmap_n % e->rmap_cap] = root;
         e->rmap_n++;
         e->rmap_n_bcast++;
@@ -987,6 +989,57 @@ int32_t roam_bcast_keyframe(roam_ctx *ctx, int32_t root, int32_t lane, roam_keyf
         if (P > 0) HIP_TRY(ctx, hipMemcpyAsync(peaks, e->kfb + KFB_PEAKS_OFF, sizeof(int32_t) * 2 * (size_t)P, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ROAM_OK;
+}
+
+// the exchange's resources, made once for `world` ranks (a failed set-up is retried, never half used)
+static int32_t kfx_setup(roam_ctx *ctx, Engine *e, int world)
+{
+    if (e->kfx_ready) {
+        if (world > e->kfx_world) { ROAM_SET_ERR(ctx, "keyframe exchange: set up for %d ranks, asked for %d", e->kfx_world, world); return ROAM_E_STATE; }
+        return ROAM_OK;
+    }
+    e->kfx_peaks = std::min(e->cfg.peaks_cap, 32768);
+    e->kfx_rec = KFB_PEAKS_OFF + (size_t)e->kfx_peaks * 8;
+    if (!e->st_comm) HIP_TRY(ctx, hipStreamCreateWithFlags(&e->st_comm, hipStreamNonBlocking));
+    for (auto &ev : e->ev_kfx) if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!e->kfx_send && !dalloc(ctx, e, &e->kfx_send, e->kfx_rec)) return ROAM_E_HIP;
+    if (!e->kfx_recv && !dalloc(ctx, e, &e->kfx_recv, e->kfx_rec * (size_t)world)) return ROAM_E_HIP;
+    if (!e->rmap_n_dev && !dalloc(ctx, e, &e->rmap_n_dev, 1)) return ROAM_E_HIP;
+    if (!e->rmap_root_dev && !dalloc(ctx, e, &e->rmap_root_dev, (size_t)e->rmap_cap)) return ROAM_E_HIP;
+    HIP_TRY(ctx, hipMemsetAsync(e->rmap_n_dev, 0, sizeof(int64_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    e->kfx_world = world;
+    e->kfx_ready = true;
+    return ROAM_OK;
+}
+
+// test / debug: the RECEIVE half of roam_keyframe_exchange on one GPU.  `recv` (host) holds `world` records as the ncclAllGather of a
+// `world`-rank job leaves them in every rank's receive buffer - record r = rank r's, *rec_bytes apart (header at 0, locals at
+// *locals_off, peaks at *peaks_off) - and goes through the SAME kfx_append_kernel, on the exchange stream, into this rank's remote map.
+// With recv == NULL only the layout is returned.  No communicator is needed; the map must be reserved with at least `world` slots.
+int32_t roam_debug_keyframe_append(roam_ctx *ctx, const uint8_t *recv, int32_t world, int64_t *rec_bytes, int32_t *locals_off,
+                                   int32_t *peaks_off, int32_t *max_peaks)
+{
+    ENGINE();
+    ARG_CHECK(ctx, world >= 1 && world <= 4096);
+    if (e->rmap_cap <= 0) { ROAM_SET_ERR(ctx, "debug_keyframe_append: reserve the remote map first"); return ROAM_E_STATE; }
+    if (e->rmap_cap < world) { ROAM_SET_ERR(ctx, "debug_keyframe_append: remote map of %d slots for %d ranks", e->rmap_cap, world); return ROAM_E_CAPACITY; }
+    if (e->rmap_n_bcast) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
+    { const int32_t rc_ = kfx_setup(ctx, e, world); if (rc_ != ROAM_OK) return rc_; }
+    if (rec_bytes) *rec_bytes = (int64_t)e->kfx_rec;
+    if (locals_off) *locals_off = KFB_LOCALS_OFF;
+    if (peaks_off) *peaks_off = KFB_PEAKS_OFF;
+    if (max_peaks) *max_peaks = e->kfx_peaks;
+    if (!recv) return ROAM_OK;
+    hipStream_t st = e->st_comm;
+    HIP_TRY(ctx, hipMemcpyAsync(e->kfx_recv, recv, e->kfx_rec * (size_t)world, hipMemcpyHostToDevice, st));
+    const size_t slot_bytes = KFB_PEAKS_OFF + (size_t)e->cfg.peaks_cap * 8;
+    hipLaunchKernelGGL(kfx_append_kernel, dim3(1), dim3(256), 0, st, e->kfx_recv, world, e->kfx_rec, e->rmap, slot_bytes, e->rmap_cap,
+                       e->rmap_n_dev, e->rmap_root_dev, KS, e->kfx_peaks);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));                            // (the host buffer is the caller's again)
+    e->kfx_calls++;
     return ROAM_OK;
 }
 
@@ -1005,19 +1058,7 @@ int32_t roam_keyframe_exchange(roam_ctx *ctx, int32_t lane)
     // (the append kernel writes the records of one gather into consecutive ring slots: fewer slots than ranks would tear them)
     if (e->rmap_cap < world) { ROAM_SET_ERR(ctx, "keyframe_exchange: remote map of %d slots for %d ranks", e->rmap_cap, world); return ROAM_E_CAPACITY; }
     if (e->rmap_n_bcast) { ROAM_SET_ERR(ctx, "remote map: roam_bcast_keyframe and roam_keyframe_exchange were mixed on one engine"); return ROAM_E_STATE; }
-    if (!e->kfx_ready) {
-        e->kfx_peaks = std::min(e->cfg.peaks_cap, 32768);
-        e->kfx_rec = KFB_PEAKS_OFF + (size_t)e->kfx_peaks * 8;
-        if (!e->st_comm) HIP_TRY(ctx, hipStreamCreateWithFlags(&e->st_comm, hipStreamNonBlocking));
-        for (auto &ev : e->ev_kfx) if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        if (!e->kfx_send && !dalloc(ctx, e, &e->kfx_send, e->kfx_rec)) return ROAM_E_HIP;
-        if (!e->kfx_recv && !dalloc(ctx, e, &e->kfx_recv, e->kfx_rec * (size_t)world)) return ROAM_E_HIP;
-        if (!e->rmap_n_dev && !dalloc(ctx, e, &e->rmap_n_dev, 1)) return ROAM_E_HIP;
-        if (!e->rmap_root_dev && !dalloc(ctx, e, &e->rmap_root_dev, (size_t)e->rmap_cap)) return ROAM_E_HIP;
-        HIP_TRY(ctx, hipMemsetAsync(e->rmap_n_dev, 0, sizeof(int64_t), ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        e->kfx_ready = true;
-    }
+    { const int32_t rc_ = kfx_setup(ctx, e, world); if (rc_ != ROAM_OK) return rc_; }
     hipStream_t st = e->st_comm;
     const int rs = (int)((e->nstep - 1) % RES_RING);
     HIP_TRY(ctx, hipStreamWaitEvent(st, e->ev_res[rs], 0));            // the step's records (and with them its keyframe state) are final

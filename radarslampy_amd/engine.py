@@ -81,6 +81,16 @@ class Engine:
         """collective, non-blocking (roam_keyframe_exchange): call on every rank after each step"""
         self.ctx.check(self.lib.roam_keyframe_exchange(self.ctx.h, int(lane)))
 
+    def debug_keyframe_append(self, recv: np.ndarray = None, world: int = 1):
+        """test / debug (roam_debug_keyframe_append): `recv` = (world, rec_bytes) u8 as an all-gather would leave it -> this rank's remote
+        map, through the exchange's own append kernel.  Returns the record layout dict(rec_bytes, locals_off, peaks_off, max_peaks)."""
+        rb, lo, po, mp = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        if recv is not None:
+            recv = np.ascontiguousarray(recv, np.uint8)
+        self.ctx.check(self.lib.roam_debug_keyframe_append(self.ctx.h, _ffi._ptr(recv) if recv is not None else None, int(world),
+                                                           C.byref(rb), C.byref(lo), C.byref(po), C.byref(mp)))
+        return dict(rec_bytes=rb.value, locals_off=lo.value, peaks_off=po.value, max_peaks=mp.value)
+
     def remote_map_count(self):
         """(keyframes received so far, keyframes resident in the ring)"""
         rec, res = C.c_int64(0), C.c_int32(0)
