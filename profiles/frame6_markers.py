@@ -56,7 +56,11 @@ def compare(m, pts, a, bx, by, rad=2.4):
     for j, (x, y) in enumerate(pts):
         cx, cy = a * x + bx, a * y + by
         yy, xx = np.mgrid[int(cy) - 3:int(cy) + 5, int(cx) - 3:int(cx) + 5]
-        d = (xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad
+        ok = (yy >= 0) & (yy < m.shape[0]) & (xx >= 0) & (xx < m.shape[1])          # (a point at the picture's edge)
+        yy, xx = np.clip(yy, 0, m.shape[0] - 1), np.clip(xx, 0, m.shape[1] - 1)
+        d = ((xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad) & ok
+        if d.sum() == 0:
+            continue
         if (m[yy, xx] & d).sum() / d.sum() < 0.45:
             unmarked.append((j, round(float(x), 1), round(float(y), 1)))
     return blobs, unmarked
@@ -77,11 +81,11 @@ def main():
     cart0 = oracle.convertPolarImageToCartesian(pay[0].astype(np.float32) / np.float32(255.))
     pipe = oracle.OdometryPipeline(np.ascontiguousarray(pay[0]), oracle.append_dedupe(np.empty((0, 2)), detect(cart0)), traj["gt_pose"][0],
                                    detect=detect, payload_off=0, clip=pay.shape[2], keyframe_trans_m=0.0)
-    for t in range(1, 8):
+    for t in range(1, 11):
         frame[0] = t
         pipe.step(np.ascontiguousarray(pay[t]))
     oracle.rejectOutliers = real
-    masks = {k: yellow_mask(k) for k in (2, 3, 5, 6, 7)}
+    masks = {k: yellow_mask(k) for k in (2, 3, 5, 6, 7, 8, 9, 10)}
     best = None
     for a in np.linspace(0.1992, 0.2004, 13):
         for bx in np.linspace(85.5, 86.75, 11):
@@ -91,11 +95,13 @@ def main():
                     best = (s, a, bx, by)
     _, a, bx, by = best
     print("display transform: a %.5f bx %.3f by %.3f (mean IoU %.3f on frames 2, 3, 5)" % (a, bx, by, best[0]))
-    for k in (2, 3, 5, 6, 7):
+    for k in (2, 3, 5, 6, 7, 8, 9, 10):
         pts = rec[k]["prev"][rec[k]["mask"]]
         print("frame %d: %d inliers, IoU %.3f, unexplained yellow blobs / unmarked points:" % (k, len(pts), iou(masks[k], pts, a, bx, by)), *compare(masks[k], pts, a, bx, by))
-    for i, m in enumerate(rec[6]["masks"]):
-        print("frame 6, tied clique %d (leaves out %s):" % (i, np.where(~m)[0].tolist()), *compare(masks[6], rec[6]["prev"][m], a, bx, by))
+    for f in (6, 8, 9, 10):                                      # (round 6: frames 8-10 added)
+        for i, m in enumerate(rec[f]["masks"]):
+            print("frame %d, tied clique %d of %d (leaves out %s):" % (f, i, len(rec[f]["masks"]), np.where(~m)[0].tolist()),
+                  *compare(masks[f], rec[f]["prev"][m], a, bx, by))
 
 
 if __name__ == "__main__":

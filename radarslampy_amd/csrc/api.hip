@@ -68,7 +68,17 @@ int32_t roam_device_info(roam_ctx *ctx, char *name, int32_t name_cap, int32_t *c
     if (!ctx) return ROAM_E_ARG;
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    if (name && name_cap > 0) { strncpy(name, prop.name, name_cap - 1); name[name_cap - 1] = 0; }
+    if (name && name_cap > 0) {
+        strncpy(name, prop.name, name_cap - 1); name[name_cap - 1] = 0;
+        if (!name[0]) {
+            // some driver stacks leave the marketing name empty: say what the properties say (gfx950 with 256 CUs is the MI350 series,
+            // its 2.4 GHz part the MI355X)
+            const bool mi35x = strncmp(prop.gcnArchName, "gfx950", 6) == 0 && prop.multiProcessorCount == 256;
+            snprintf(name, (size_t)name_cap, "%s (%.6s, %d CUs, %.0f GB, %.2f GHz)",
+                     mi35x ? (prop.clockRate >= 2300000 ? "AMD Instinct MI355X" : "AMD Instinct MI350X") : "AMD GPU", prop.gcnArchName,
+                     prop.multiProcessorCount, (double)prop.totalGlobalMem / 1073741824.0, prop.clockRate * 1e-6);
+        }
+    }
     if (arch && arch_cap > 0) { strncpy(arch, prop.gcnArchName, arch_cap - 1); arch[arch_cap - 1] = 0; }
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;

@@ -553,6 +553,10 @@ __device__ __forceinline__ int nx_reorder_small(int lane, int kv, int sv, uint64
 //     result (see nx_phase), the rounds needed are the longest chain of displacements: two or three at these load factors.
 __shared__ uint32_t nx_Tw[2][128];                  // one per wavefront
 __shared__ uint16_t nx_ck[2][32], nx_cv[2][32];      // [ci][0..18] the keys / the outcome, [ci][19] of nx_ck: 1 = valid
+// INVARIANT: the memo is indexed by CHAIN (ci), not by wavefront.  It is race-free because each chain belongs to one wavefront at a
+// time: chain 0 (the subg chain) only ever runs on the first wavefront, chain 1 (the cand chain) on the helper between the two mailbox
+// barriers of a level - and the first wavefront never builds a chain-1 table (tab[2] / tab[3]) between those barriers.  A change that
+// lets both wavefronts build tables of one chain at once needs a memo per wavefront.
 __device__ __forceinline__ int nx_probe_T(const uint32_t *nx_T, int key, int idx, int mask)
 {
     unsigned perturb = (unsigned)key, i0 = (unsigned)key & (unsigned)mask;
@@ -1216,13 +1220,15 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void max_clique_kernel(const uint64
 
 // order[0..B) = the problems by falling number of correspondences (a counting sort in one workgroup): the kernel's time is set by its
 // longest problems - the pairs right after a re-detection - and a workgroup that starts last should not be one of them
+// (bucket = 1024 - clamp(count, 0, K) >> shift: a negative count sorts as 0, and K >> shift above 1024 saturates into bucket 0 - the
+// caller picks shift so that it does not: launch_order_by_count)
 __global__ __launch_bounds__(1024) void cq_order_kernel(const int32_t *__restrict__ count, int B, int K, int32_t *__restrict__ order, int shift)
 {
     __shared__ int hist[1026];
     const int t = threadIdx.x;
     for (int i = t; i <= 1025; i += 1024) hist[i] = 0;
     __syncthreads();
-    for (int i = t; i < B; i += 1024) atomicAdd(&hist[1024 - min(min(count[i], K) >> shift, 1024)], 1);       // bucket 0 = the largest problems
+    for (int i = t; i < B; i += 1024) atomicAdd(&hist[1024 - min(max(min(count[i], K), 0) >> shift, 1024)], 1);       // bucket 0 = the largest problems
     __syncthreads();
     if (t < 64) {                                                                                   // exclusive prefix over 1025 buckets: 17 per lane
         int loc[17], sum = 0;
@@ -1233,11 +1239,12 @@ __global__ __launch_bounds__(1024) void cq_order_kernel(const int32_t *__restric
         for (int k = 0; k < 17; k++) { const int i = t * 17 + k; if (i <= 1024) hist[i] = run; run += loc[k]; }
     }
     __syncthreads();
-    for (int i = t; i < B; i += 1024) order[atomicAdd(&hist[1024 - min(min(count[i], K) >> shift, 1024)], 1)] = i;
+    for (int i = t; i < B; i += 1024) order[atomicAdd(&hist[1024 - min(max(min(count[i], K), 0) >> shift, 1024)], 1)] = i;
 }
 
 hipError_t launch_order_by_count(hipStream_t st, const int32_t *count, int B, int cmax, int32_t *order, int shift)
 {
+    if (shift < 0 || shift > 30 || (cmax >> shift) > 1024) return hipErrorInvalidValue;             // the 1025 buckets would saturate
     hipLaunchKernelGGL(cq_order_kernel, dim3(1), dim3(1024), 0, st, count, B, cmax, order, shift);
     return hipGetLastError();
 }

@@ -117,6 +117,8 @@ struct Engine {
     hipEvent_t tr_ev[64][6] = {};
     hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
+    bool tr_ev_ok[64] = {};                          // the step recorded its front-end event pairs (stage events were on when it was enqueued)
+    int64_t stage_ev_step = -1;                     // the step whose ev[] (back-end stage events) are valid, -1: none
     bool tr_ok = false;
     unsigned long long *pyr_dark = nullptr;        // lanes of the 2024 -> 1012 pyramid kernel that see nothing but pixels beyond the maximum range
     static constexpr bool warp_dark_zero = true;   // the pyramids are zero-filled at creation and level 0 is written by the warp only:
@@ -555,6 +557,23 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     return ROAM_OK;
 }
 
+// the fused detection variant's tables and per-slot scratch, made when first needed (dead weight otherwise)
+static int32_t fused_tables(roam_ctx *ctx, Engine *e)
+{
+    RtArgs &r = e->rt;
+    if (r.fd_mapT) return ROAM_OK;
+    const size_t npx = (size_t)e->W * e->W, R = (size_t)r.slots;
+    uint32_t *mapT = nullptr, *boxtab = nullptr, *darktab = nullptr;
+    bool ok = dalloc(ctx, e, &mapT, npx) && dalloc(ctx, e, &boxtab, retrack_fused_boxtab_words(e->W)) && dalloc(ctx, e, &darktab, retrack_darktab_words(e->W));
+    ok = ok && dalloc(ctx, e, &r.fd_halo, R * 2 * (size_t)r.fd_halo_words) && dalloc(ctx, e, &r.fd_cc, R * 2048);
+    if (!ok) return ROAM_E_HIP;
+    HIP_TRY(ctx, launch_retrack_fused_tables(ctx->stream, e->warp_map, e->W, e->cfg.clip, mapT, boxtab, darktab));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    r.fd_boxtab = boxtab; r.fd_darktab = darktab;
+    r.fd_mapT = mapT;                                   // (set last: the null check of launch_retrack_part is the "ready" test)
+    return ROAM_OK;
+}
+
 int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
 {
     if (!ctx) return ROAM_E_ARG;
@@ -662,13 +681,11 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         // bound by instruction issue, not by HBM - so the two-kernel form stays the default.  Its tables: transposed sampling map,
         // footprints and dark steps per band; per slot: two hand-off buffers + the column totals
         {
+            // (its buffers - 1 MB of hand-off scratch per slot, 0.55 GB at 512 slots, and three tables - exist only when the variant is
+            // asked for: by the environment here, by roam_engine_debug_detect / roam_engine_time_kernel("doh_fused") on first use)
             const char *fv = getenv("ROAM_FUSED_DETECT");
             r.fused = (fv && fv[0] == '1') ? 1 : 0;
             r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
-            ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.fd_mapT), npx);
-            ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.fd_boxtab), retrack_fused_boxtab_words(e->W));
-            ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.fd_darktab), retrack_darktab_words(e->W));
-            ok = ok && dalloc(ctx, e, &r.fd_halo, (size_t)R * 2 * (size_t)r.fd_halo_words) && dalloc(ctx, e, &r.fd_cc, (size_t)R * 2048);
         }
         // candidate lists and bookkeeping tables per DETECTION (0.9 MB each): K4-K7 run once per step over all of them
         const size_t D = (size_t)B;
@@ -723,8 +740,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     HIP_TRY(ctx, launch_pyr_dark(ctx->stream, e->warp_map, e->W, e->W, cfg->clip, e->pyr_dark));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_boxtab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.boxtab)));
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_darktab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.darktab)));
-    if (e->rt_on) HIP_TRY(ctx, launch_retrack_fused_tables(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.fd_mapT),
-                                                           const_cast<uint32_t *>(e->rt.fd_boxtab), const_cast<uint32_t *>(e->rt.fd_darktab)));
+    if (e->rt_on && e->rt.fused) { const int32_t rc_ = fused_tables(ctx, e); if (rc_ != ROAM_OK) { roam_engine_destroy(ctx); return rc_; } }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ROAM_OK;
 }
@@ -1244,6 +1260,8 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     for (int b = 0; b < B; b++) { hs[b] = scan_idx[b] & ~ROAM_STEP_NEW_SEQUENCE; hs[B + b] = (scan_idx[b] & ROAM_STEP_NEW_SEQUENCE) ? 1 : 0; }
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * 2 * (size_t)B, hipMemcpyHostToDevice, sA));
     hipEvent_t *tr = e->tr_ev[e->nstep & 63];
+    e->tr_ev_ok[e->nstep & 63] = e->stage_ev;       // (the switch may be flipped between steps: every step remembers what it recorded)
+    if (e->stage_ev) e->stage_ev_step = e->nstep;
     // the peak kernel gets its own stream: it only needs the scan indices (event ev_idx) and is joined before g4
     hipStream_t sP = ctx->stream5;
     HIP_TRY(ctx, hipEventRecord(e->ev_idx, sA));
@@ -1452,6 +1470,7 @@ int32_t roam_engine_stage_times(roam_ctx *ctx, float *ms_out, const char **names
     ARG_CHECK(ctx, ms_out && n && cap >= ST_COUNT);
     if (!e->stepped) { ROAM_SET_ERR(ctx, "no step recorded"); return ROAM_E_STATE; }
     if (!e->stage_ev) { ROAM_SET_ERR(ctx, "stage events are off (roam_engine_set_stage_events)"); return ROAM_E_STATE; }
+    if (e->stage_ev_step != e->nstep - 1) { ROAM_SET_ERR(ctx, "the last step was enqueued with stage events off: run a step first"); return ROAM_E_STATE; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < ST_COUNT; i++) {
         float ms = 0;
@@ -1496,14 +1515,16 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
         *n_used = (int32_t)used;
         return ROAM_OK;
     }
+    int64_t used = 0;
     for (int64_t i = e->nstep - n; i < e->nstep; i++) {
+        if (!e->tr_ev_ok[i & 63]) continue;                                   // enqueued while the events were switched off
         float ms = 0;
         const int a0 = k == 2 ? 3 : (k == 1 ? 1 : 0), a1 = k == 2 ? 4 : (k == 1 ? 2 : 5);   // peaks and pyramid: their own streams' pairs
         HIP_TRY(ctx, hipEventElapsedTime(&ms, e->tr_ev[i & 63][a0], e->tr_ev[i & 63][a1]));
-        sum += ms;
+        sum += ms; used++;
     }
-    *avg_ms = (float)(sum / (double)n);
-    *n_used = (int32_t)n;
+    *avg_ms = used ? (float)(sum / (double)used) : 0.f;
+    *n_used = (int32_t)used;
     return ROAM_OK;
 }
 
@@ -1567,6 +1588,7 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             if (!e->rt_on) { hipEventDestroy(a); hipEventDestroy(b); ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
             // ("doh_fused:<d>": with diagnostics word d - ablations of retrack_fused.inc, measurement only)
             const int P = e->rt.slots, which = !strcmp(name, "doh_integral") ? 0 : (!strcmp(name, "doh_det_maxima") ? 1 : 2 + (name[9] == ':' ? atoi(name + 10) : 0));
+            if (which >= 2) { const int32_t rc_ = fused_tables(ctx, e); if (rc_ != ROAM_OK) return rc_; }       // (made on first use)
             if (r == 0) {
                 std::vector<int32_t> sc(P);
                 for (int i = 0; i < P; i++) sc[i] = e->last_scan[i % B] >= 0 ? e->last_scan[i % B] : 0;
@@ -1625,6 +1647,7 @@ int32_t roam_engine_debug_detect(roam_ctx *ctx, int32_t fused, int32_t n_slots, 
     HIP_TRY(ctx, hipMemcpy(e->rt.rt_scan, sc.data(), sizeof(int32_t) * (size_t)P, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(e->rt.rt_n, &P, sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemsetAsync(e->rt.cand_n, 0, sizeof(int32_t) * (size_t)P, st));
+    if (fused) { const int32_t rc_ = fused_tables(ctx, e); if (rc_ != ROAM_OK) return rc_; }
     if (fused) HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, S_out ? 3 : 2));
     else { HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, 0)); HIP_TRY(ctx, launch_retrack_part(st, e->rt, P, 1)); }
     HIP_TRY(ctx, launch_retrack_emit(st, e->rt, P));

@@ -41,9 +41,9 @@ def test_full_seq_1_streaming(md):
         # dead-reckoned over 9 km: the drift stays below 1.5 % of the distance driven with the motion-distortion solve (the paper
         # reports 41.8 m on the real data) and below 3 % with plain Kabsch dead reckoning
         assert rmse < (0.015 if md else 0.03) * dist and hd < 0.2, (rmse, hd)
-        # the run is deterministic (seeded rendering, exact kernels): THE committed figures (profiles/r04_full_seq_1_md_*.json), so
-        # that "this kernel change was exact" is a test.  Round 4 moved them once, on purpose: the clique tie-break is now the
+        # the run is deterministic (seeded rendering, exact kernels): THE committed figures (tests/golden/full_seq_1_figures.json), so
+        # that "this kernel change was exact" is a test - a determinism check, not a parity reference.  Round 4 moved them once, on purpose: the clique tie-break is now the
         # reference's (rounds 2-3, lexicographic tie-break: 56.295 m / 178.9 m)
-        want = json.load(open(os.path.join(HERE, "..", "profiles", f"r04_full_seq_1_md_{'on' if md else 'off'}.json")))
+        want = json.load(open(os.path.join(HERE, "golden", "full_seq_1_figures.json")))["md_on" if md else "md_off"]
         assert abs(rmse - want["position_rmse_m"]) <= 1e-3 and abs(hd - want["heading_rmse_rad"]) <= 1e-5, (rmse, hd, want)
         assert (n_rt, n_kf) == (want["retracks"], want["keyframes"]), (n_rt, n_kf, want)
