@@ -599,11 +599,12 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             out["config"]["whole_path_Bmin_GBs_per_gpu"] = round(13.07e6 * (value / world) / 1e9, 3)   # SURVEY 8d B_min per steady pair ONLY
             # steady bytes of every scan + the strict bytes of every re-detection (polar payload + f64 integral image written, then read
             # once: 66.4 MB) over the step time: what the whole step moves algorithmically
-            if rps:
-                W_ = 2 * (eng.cfg.clip // 2)
-                det_bytes = eng.cfg.rows * eng.cfg.clip + 2 * 8.0 * W_ * W_
-                out["config"]["whole_step_algorithmic_GBs"] = round((13.07e6 * B + det_bytes * float(np.mean(rps))) / (dt / args.steps) / 1e9, 1)
             out["roofline"] = roofline(eng, args, B // max(1, len(engs)), out["config"].get("retrack_fraction") or 0.0, live)
+            if rps and "algorithmic_bytes_per_detection" in out["roofline"]:
+                # (round 6: the integral image counts with the part of it that exists - the tiles the determinant kernel reads, 87.7 % of a
+                # 2024 x 2024 image - written once and read once; rounds 2-5 counted the whole image twice: 66.4 MB)
+                det_bytes = out["roofline"]["algorithmic_bytes_per_detection"]
+                out["config"]["whole_step_algorithmic_GBs"] = round((13.07e6 * B + det_bytes * float(np.mean(rps))) / (dt / args.steps) / 1e9, 1)
             if world == 1:
                 out["cpu_baseline"] = cpu_baseline(args, seqs, cyc)
     for en in engs:
@@ -728,6 +729,9 @@ def roofline(eng, args, B, retrack_fraction, live_all):
                                         "valu_issue": None if valu_frac is None else round(valu_frac, 3),
                                         "lds_array": None if lds_frac is None else round(lds_frac, 3)},
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+            **({"algorithmic_bytes_per_detection": round((iso["doh_integral"][1] + iso["doh_det_maxima"][1]) / slots, 1),
+                "frac_whole_image_bytes_as_rounds_2_to_5": round(units * (eng.cfg.rows * eng.cfg.clip * (dom == "doh_integral") + 8.0 * W_ * W_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+               if slots and dom.startswith("doh") else {}),
             "units_per_launch": round(units, 1),
             "isolated_achieved": round(iso_frac * HBM_PEAK_GBS, 2), "isolated_frac": round(iso_frac, 5),
             "kernel_ms_per_step_alone": {k: round(v, 4) for k, v in per_step.items()},

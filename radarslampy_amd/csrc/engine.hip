@@ -117,6 +117,7 @@ struct Engine {
     hipEvent_t tr_ev[64][6] = {};
     hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
+    int64_t rt_image_px = 0;                        // pixels of the integral image that are written and read (the needed tiles of the phase list)
     bool tr_ev_ok[64] = {};                          // the step recorded its front-end event pairs (stage events were on when it was enqueued)
     int64_t stage_ev_step = -1;                     // the step whose ev[] (back-end stage events) are valid, -1: none
     bool tr_ok = false;
@@ -674,6 +675,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         ok = ok && dalloc(ctx, e, &r.S, (size_t)r.SP * e->W * R);
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.boxtab), retrack_boxtab_words(e->W));
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.darktab), retrack_darktab_words(e->W));
+        ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.phlist), retrack_phase_words(e->W));
         ok = ok && dalloc(ctx, e, &r.colT, (size_t)std::min(R, RT_TWO_PASS_SLOTS) * ((e->W + 63) / 64) * e->W);
         // the fused detection kernel (retrack_fused.inc: integral image + determinants + maxima without the float64 image in HBM) serves
         // chunks of >= RT_TWO_PASS_SLOTS detections when ROAM_FUSED_DETECT=1 asks for it.  It is bit-identical to the two-kernel form
@@ -742,6 +744,20 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_darktab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.darktab)));
     if (e->rt_on && e->rt.fused) { const int32_t rc_ = fused_tables(ctx, e); if (rc_ != ROAM_OK) { roam_engine_destroy(ctx); return rc_; } }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e->rt_on && e->W <= 2048) {
+        // the phases the one-sweep integral kernel walks: from the sampling map and the dark-step table just made (host code, once)
+        const size_t npx = (size_t)e->W * e->W, ndt = retrack_darktab_words(e->W);
+        std::vector<uint32_t> mh(npx), dh(ndt), ph(retrack_phase_words(e->W), 0u);
+        HIP_TRY(ctx, hipMemcpy(mh.data(), e->warp_map, npx * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(dh.data(), e->rt.darktab, ndt * 4, hipMemcpyDeviceToHost));
+        if (!retrack_build_phases(mh.data(), dh.data(), e->W, cfg->clip, ph.data())) { ROAM_SET_ERR(ctx, "retrack: phase list"); roam_engine_destroy(ctx); return ROAM_E_ARG; }
+        HIP_TRY(ctx, hipMemcpy(const_cast<uint32_t *>(e->rt.phlist), ph.data(), ph.size() * 4, hipMemcpyHostToDevice));
+        for (uint32_t i = 0; i < ph[0]; i++) {
+            const int band = (int)(ph[1 + i] & 255u), g = (int)((ph[1 + i] >> 8) & 15u), hrows = std::min(16, e->W - 16 * band);
+            for (int w = 0; w < 4; w++)
+                if ((ph[1 + i] >> (12 + w)) & 1u) e->rt_image_px += (int64_t)hrows * std::max(0, std::min(64, e->W - (g * 256 + 64 * w)));
+        }
+    }
     return ROAM_OK;
 }
 
@@ -1606,7 +1622,10 @@ int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, f
             // out of L2: not input data, not counted since round 4); determinants + maxima = float64 image read once (the
             // candidates it writes are a few KB)
             // the fused kernel: the polar payload is all a detection reads; the float64 image never leaves the CU
-            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + npx * 8.0) : (which == 1 ? npx * 8.0 : (double)c.rows * c.clip));
+            // round 6: the part of the image that exists - the tiles the determinant kernel reads, the only ones the integral kernel
+            // writes (retrack_build_phases): 87.7 % of a 2024 x 2024 image; rounds 2-5 counted the whole image for both kernels
+            const double ipx = e->rt_image_px > 0 ? (double)e->rt_image_px : npx;
+            bytes = (double)P * (which == 0 ? ((double)c.rows * c.clip + ipx * 8.0) : (which == 1 ? ipx * 8.0 : (double)c.rows * c.clip));
         } else if (!strcmp(name, "pyramid")) {
             HIP_TRY(ctx, launch_build_pyramid(st, next, e->pd, B, e->pyr_dark));
             double rd = 0, wr = 0;

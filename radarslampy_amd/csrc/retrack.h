@@ -14,6 +14,7 @@ struct RtArgs {
     // engine state
     const uint8_t *pool;
     const uint32_t *map;
+    const uint32_t *phlist;         // the phases the one-sweep integral kernel walks (retrack_build_phases): [0] = count, then the phases
     const uint32_t *boxtab;         // per (band, group, column wave) of the one-sweep integral kernel: the polar footprint of the patch,
                                     // {min ix | max ix << 16, min iy | max iy << 16} (max ix = 0xffff: nothing inside the maximum range)
     const uint32_t *darktab;        // per column strip of the determinant kernel: which steps see nothing but pixels beyond the maximum range
@@ -72,6 +73,10 @@ hipError_t launch_retrack_emit(hipStream_t st, const RtArgs &a, int P);
 hipError_t retrack_init();
 // fills boxtab (retrack_boxtab_words(W) uint32 words) from the sampling map: geometry only, once per engine
 size_t retrack_boxtab_words(int W);
+// the phase list of the one-sweep integral kernel from the sampling map and the determinant kernel's dark-step table (both on the HOST):
+// out = retrack_phase_words(W) uint32.  false: the image is too large for the one-sweep kernel (it is not used then)
+size_t retrack_phase_words(int W);
+bool retrack_build_phases(const uint32_t *map_host, const uint32_t *darktab_host, int W, int cols, uint32_t *out);
 hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *boxtab);
 // fills darktab (retrack_darktab_words(W) zero-initialised uint32 words) from the sampling map: geometry only, once per engine
 size_t retrack_darktab_words(int W);

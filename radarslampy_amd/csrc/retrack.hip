@@ -211,11 +211,14 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #ifndef RI_LDS_PAD
 #define RI_LDS_PAD 0                        // (occupancy experiments: profiles/build_variant.py)
 #endif
-#ifndef RI_SINGLE_BUF
-#define RI_SINGLE_BUF 0                     // 1: ONE tile buffer (half the LDS: four workgroups per CU), the taps of A(i+1) overlap B(i), the tile accesses do not
+// (round 6, measured and dropped: ONE tile buffer with the taps of A(i + 1) beside B(i) - half the LDS, so four workgroups per CU - is
+// bit-identical and slower: 6.90 ms per 512 detections against 6.58 at two workgroups per CU, 16.9 us per detection at three; eight column
+// waves per workgroup on one buffer: 10.2 ms.  More waves per CU make this kernel slower, not faster - profiles/r06_detection_experiments.txt)
+#ifndef RI_PHASE_SKIP
+#define RI_PHASE_SKIP 1                     // walk the list of phases that matter (retrack_build_phases) instead of all bands x groups
 #endif
-#define RI_NBUF (RI_SINGLE_BUF ? 1 : 2)
-#define RI_LDS_BYTES (RI_NBUF * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
+#define RI_PHL_MAX 1024                     // phases of the largest image of the one-sweep kernel (128 bands x 8 groups)
+#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
 struct __attribute__((packed)) RtU16 { uint16_t v; };
 struct __attribute__((packed)) RtU32 { uint32_t v; };
 #ifndef RI_BOX
@@ -282,8 +285,22 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
     const int nbands = (H + RI_ROWS - 1) / RI_ROWS;
     __shared__ float lut[256];
     __shared__ __align__(4) uint8_t box[RI_WAVES][RI_BOX];
+    // the phases to walk: band | group << 8 | (tiles the determinant kernel reads, one bit per column wave) << 12, in sweep order
+    // (retrack_build_phases: a phase is left out when nothing in it is lit and its row sums are either still zero or never read again)
+    __shared__ uint16_t phl[RI_PHL_MAX];
     if (t < 256) lut[t] = rt_code_to_f32(t);
+#if RI_PHASE_SKIP
+    const int nph = (int)a.phlist[0];
+    for (int i = t; i < nph; i += (int)blockDim.x) phl[i] = (uint16_t)a.phlist[1 + i];
+#else
+    const int nph = nbands * RI_GROUPS;
+    for (int i = t; i < nph; i += (int)blockDim.x) phl[i] = (uint16_t)((i / RI_GROUPS) | ((i % RI_GROUPS) << 8) | (((1u << RI_WAVES) - 1u) << 12));
+#endif
     __syncthreads();
+    // (an entry is read once - one LDS read a phase, a phase ahead - and passed on as a scalar)
+    auto ph_ent = [&](int i) { return i < nph ? (int)__builtin_amdgcn_readfirstlane((int)phl[i]) : 0; };
+    auto ph_band = [](int e) { return e & 255; };
+    auto ph_group = [](int e) { return (e >> 8) & 15; };
     if (wave < RI_WAVES) {
         // ------------------------------------------------------------------------------------ column waves: C(i-1), A(i+1)
         const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 #endif
         };
         float v[RI_ROWS];                                                  // the pixels of the phase A1 has prepared for A2
-        auto A1 = [&](int band, int g) {
+        auto A1 = [&](int i, int e_n1, int e_n2) {                         // phase i of the list: the patch's pixels -> v[]; e_n1 / e_n2: the entries of the next two phases
             // The polar footprint of the wave's 64 x 16 pixel patch is a small box (range span x azimuth span, a few hundred bytes):
             // it is copied into LDS with a handful of coalesced row loads (16 lanes per polar row, four rows per instruction) and
             // the 4 taps per pixel become LDS byte reads; per-lane byte gathers from global memory (two 16-bit loads per pixel,
@@ -414,22 +431,27 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                 for (int k = 0; k < RI_ROWS; k++) v[k] = rt_pixel(m[k], p, rows, cols, stride, lut);
             }
             // the next phase's map words leave now; they land while the row wave works
-            {
-                const int i1 = band * RI_GROUPS + g + 1;
-                if (i1 < nbands * RI_GROUPS) {
-                    fetch(i1 / RI_GROUPS, i1 % RI_GROUPS);
-                    prefetch_box();
-                    if (i1 + 1 < nbands * RI_GROUPS) fetch_ext(i1 + 1);
-                }
+            if (i + 1 < nph) {
+                fetch(ph_band(e_n1), ph_group(e_n1));
+                prefetch_box();
+                if (i + 2 < nph) fetch_ext(ph_band(e_n2) * RI_GROUPS + ph_group(e_n2));
             }
         };
-        auto A2 = [&](int band, int g) {
+        int gcur = 0;                                                      // the group whose running sums sit in acc[0]
+        auto A2 = [&](int i, int band, int g) {
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
-            Tile &tl = tiles[(RI_SINGLE_BUF ? 0 : ((band * RI_GROUPS + g) & 1)) * RI_WAVES + wave];
+            Tile &tl = tiles[(i & 1) * RI_WAVES + wave];
             {
-                // acc[0] is always the running sum of the CURRENT group's column: the groups come round in order, so the array is
-                // rotated by one after every phase (8 register moves; a group-indexed array was kept in scratch memory by the
-                // compiler: 16 MB of extra HBM writes per detection)
+                // acc[0] is always the running sum of the CURRENT group's column: the array is rotated by one after every phase (8
+                // register moves; a group-indexed array was kept in scratch memory by the compiler: 16 MB of extra HBM writes per
+                // detection) - and by as many groups as the phase list leaves out in between (their pixels are dark: sums unchanged)
+                while (gcur != g) {
+                    const double s0 = acc[0];
+#pragma unroll
+                    for (int q = 0; q + 1 < RI_GROUPS; q++) acc[q] = acc[q + 1];
+                    acc[RI_GROUPS - 1] = s0;
+                    gcur = (gcur + 1) % RI_GROUPS;
+                }
                 double s = acc[0];
                 if (c < W) {
 #pragma unroll
@@ -441,12 +463,15 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 #pragma unroll
                 for (int q = 0; q + 1 < RI_GROUPS; q++) acc[q] = acc[q + 1];
                 acc[RI_GROUPS - 1] = s;
+                gcur = (gcur + 1) % RI_GROUPS;
             }
         };
-        auto C = [&](int band, int g) {
+        auto C = [&](int i, int e) {
+            const int band = ph_band(e), g = ph_group(e);
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
-            const Tile &tl = tiles[(RI_SINGLE_BUF ? 0 : ((band * RI_GROUPS + g) & 1)) * RI_WAVES + wave];
-            if (c < W) {
+            const Tile &tl = tiles[(i & 1) * RI_WAVES + wave];
+            const bool wanted = ((e >> (12 + wave_u)) & 1) != 0;              // does anything read this tile?
+            if (c < W && wanted) {
                 double *q = S + (int64_t)band * RI_ROWS * SP + c;
                 const int nk = min(RI_ROWS, H - band * RI_ROWS);
                 if (nk == RI_ROWS) {
@@ -456,42 +481,40 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                     for (int k = 0; k < nk; k++) q[(int64_t)k * SP] = tl[k][lane];
             }
         };
-        const int nphase = nbands * RI_GROUPS;
-        fetch(0, 0);
-        fetch_ext(0);
-        prefetch_box();
-        if (nphase > 1) fetch_ext(1);
-        A1(0, 0);
-#if RI_SINGLE_BUF
+        // entries of phases i - 1 .. i + 3 as scalars
+        int e_m1 = 0, e_0 = ph_ent(0), e_1 = ph_ent(1), e_2 = ph_ent(2), e_3 = ph_ent(3);
+        if (nph > 0) {
+            fetch(ph_band(e_0), ph_group(e_0));
+            fetch_ext(ph_band(e_0) * RI_GROUPS + ph_group(e_0));
+            prefetch_box();
+            if (nph > 1) fetch_ext(ph_band(e_1) * RI_GROUPS + ph_group(e_1));
+            A1(0, e_1, e_2);
+            A2(0, ph_band(e_0), ph_group(e_0));
 #pragma unroll 1
-        for (int i = 0; i < nphase; i++) {
-            A2(i / RI_GROUPS, i % RI_GROUPS);
-            __syncthreads();                                               // tile i is complete: B(i) runs ..
-            if (i + 1 < nphase) A1((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS);   // .. beside the taps of phase i + 1 (registers only)
-            __syncthreads();                                               // B(i) is complete
-            C(i / RI_GROUPS, i % RI_GROUPS);
-        }
-#else
-        A2(0, 0);
-#pragma unroll 1
-        for (int i = 0; i < nphase; i++) {
-            __syncthreads();                                               // A(i) and B(i-1) are complete
-            if (i > 0) C((i - 1) / RI_GROUPS, (i - 1) % RI_GROUPS);
-            if (i + 1 < nphase) { A1((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS); A2((i + 1) / RI_GROUPS, (i + 1) % RI_GROUPS); }
+            for (int i = 0; i < nph; i++) {
+                const int e_4 = ph_ent(i + 4);                             // (lands while this phase runs)
+                __syncthreads();                                           // A(i) and B(i-1) are complete
+                if (i > 0) C(i - 1, e_m1);
+                if (i + 1 < nph) { A1(i + 1, e_2, e_3); A2(i + 1, ph_band(e_1), ph_group(e_1)); }
+                e_m1 = e_0; e_0 = e_1; e_1 = e_2; e_2 = e_3; e_3 = e_4;
+            }
         }
         __syncthreads();
-        C(nbands - 1, RI_GROUPS - 1);
-#endif
+        if (nph > 0) C(nph - 1, e_m1);
     } else {
         // ------------------------------------------------------------------------------------ the row wave: B(i)
-        for (int band = 0; band < nbands; band++) {
-            double carry = 0.0;                                            // running sum of row band * RI_ROWS + lane
+        double carry = 0.0;                                                // running sum of row band * RI_ROWS + lane
+        int pband = -1;
+        int e_nx = ph_ent(0);
+        for (int i = 0; i < nph; i++) {
+            const int band = ph_band(e_nx), g = ph_group(e_nx);
+            e_nx = ph_ent(i + 1);
+            if (band != pband) { carry = 0.0; pband = band; }              // (the phases a band leaves out on its left have sums of zero)
             const bool live = lane < RI_ROWS && band * RI_ROWS + lane < H;
-            for (int g = 0; g < RI_GROUPS; g++) {
-                __syncthreads();
-                if (live) {
+            __syncthreads();
+            if (live) {
                 const int C0 = g * 64 * RI_WAVES, ncols = min(64 * RI_WAVES, W - C0);
-                Tile *tg = tiles + (RI_SINGLE_BUF ? 0 : ((band * RI_GROUPS + g) & 1)) * RI_WAVES;
+                Tile *tg = tiles + (i & 1) * RI_WAVES;
                 int j = 0;
                 if (ncols >= 16) {
                     // two batches of eight columns in flight: while one is added up (eight dependent float64 additions) and written
@@ -524,15 +547,9 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                     carry = __dadd_rn(carry, *q);
                     *q = carry;
                 }
-                }
-#if RI_SINGLE_BUF
-                __syncthreads();                                           // (outside the lanes' branch: one barrier per wave)
-#endif
             }
         }
-#if !RI_SINGLE_BUF
         __syncthreads();
-#endif
     }
 }
 
@@ -1795,6 +1812,73 @@ hipError_t launch_retrack_fused_tables(hipStream_t st, const uint32_t *map, int 
     hipLaunchKernelGGL(rf_boxtab_kernel, dim3(nblk, nband + 1), dim3(64), 0, st, mapT, W, cols, nblk, boxtab);
     // the dark steps of a band = the dark steps of a strip of the transposed image: rt_darktab_kernel on the transposed map
     return launch_retrack_darktab(st, mapT, W, cols, darktab);
+}
+
+// ---- which phases of the one-sweep integral kernel matter (host code, once per engine; geometry only).
+// The determinant kernel never reads the blocks of the integral image that only dark steps would touch (rt_darktab_kernel), so a 16-row x
+// 64-column TILE none of its strips loads need not be written; and a (band, group) PHASE none of whose tiles is needed need not be
+// computed when its row sums cannot matter: on a band's left while every column so far has seen no lit pixel (the sums are exactly
+// zero), on its right once nothing further along the band is needed.  Needed tiles contain every lit pixel (a lit pixel lies in the
+// window of a lit step), so a phase that is left out has dark pixels only: the columns' running sums pass it unchanged.
+// out[0] = number of phases, out[1..] = band | group << 8 | needed-tile bits << 12 in sweep order.
+size_t retrack_phase_words(int W) { return 1 + (size_t)((W + RI_ROWS - 1) / RI_ROWS) * RI_GROUPS; }
+
+bool retrack_build_phases(const uint32_t *map, const uint32_t *darktab, int W, int cols, uint32_t *out)
+{
+    const int H = W, nbands = (H + RI_ROWS - 1) / RI_ROWS, ns = (W + SD_OUT - 1) / SD_OUT, nt = H / SD_T + 1, NT = RI_GROUPS * RI_WAVES;
+    static_assert(RI_ROWS == SD_T, "a band of the integral kernel is a block of the determinant kernel");
+    if (nbands * RI_GROUPS > RI_PHL_MAX || nbands > 256) return false;
+    std::vector<uint8_t> need((size_t)nbands * NT, 0), lit((size_t)nbands * NT, 0);
+    std::vector<int> firstlit(W, H);
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++)
+            if ((int)(map[(size_t)r * W + c] & 4095u) < cols) {
+                lit[(size_t)(r / RI_ROWS) * NT + c / 64] = 1;
+                if (firstlit[c] == H) firstlit[c] = r;
+            }
+    for (int s = 0; s < ns; s++) {
+        const uint32_t *T = darktab + (size_t)s * SD_DT_WORDS;
+        const int t_first = (int)T[16], t_last = (int)T[17];
+        if (t_first >= nt) continue;                                        // the strip sees nothing
+        const int tb = t_first >= 1 ? ((t_first - 1) & ~3) : 0, te = std::min(nt, t_last + 2);
+        const int cbase = s * SD_OUT - 1 - SD_HL, c_lo = std::max(cbase, 0), c_hi = std::min(cbase + SD_BP, W) - 1;
+        for (int j = tb; j <= te + 3 && j < nbands; j++) {
+            const bool in_loop = j >= tb + 4;                               // (the four blocks of the prologue are always loaded)
+            if (in_loop && ((T[8 + ((j - 4) >> 5)] >> ((j - 4) & 31)) & 1u)) continue;
+            for (int k = c_lo / 64; k <= c_hi / 64; k++) need[(size_t)j * NT + k] = 1;
+        }
+    }
+    int n = 0;
+    bool sound = true;
+    for (int b = 0; b < nbands; b++) {
+        bool needp[RI_GROUPS], zero[RI_GROUPS];
+        uint32_t bits[RI_GROUPS];
+        for (int g = 0; g < RI_GROUPS; g++) {
+            bits[g] = 0; zero[g] = true;
+            for (int w = 0; w < RI_WAVES; w++) if (need[(size_t)b * NT + g * RI_WAVES + w]) bits[g] |= 1u << w;
+            needp[g] = bits[g] != 0;
+            const int rend = std::min(b * RI_ROWS + RI_ROWS - 1, H - 1);
+            for (int c = g * 64 * RI_WAVES; c < std::min(W, (g + 1) * 64 * RI_WAVES); c++) if (firstlit[c] <= rend) { zero[g] = false; break; }
+        }
+        for (int g = 0; g < RI_GROUPS; g++) {
+            bool skipL = !needp[g], skipR = true;
+            for (int q = 0; q <= g && skipL; q++) skipL = zero[q];
+            for (int q = g; q < RI_GROUPS && skipR; q++) skipR = !needp[q];
+            if (g * 64 * RI_WAVES >= W) continue;                           // (no such columns)
+            if (skipL || skipR) {
+                for (int w = 0; w < RI_WAVES; w++) if (lit[(size_t)b * NT + g * RI_WAVES + w]) sound = false;      // (cannot happen: see above)
+                continue;
+            }
+            out[1 + n++] = (uint32_t)b | ((uint32_t)g << 8) | (bits[g] << 12);
+        }
+    }
+    if (!sound) {                                                           // belt and braces: walk everything, write everything
+        n = 0;
+        for (int b = 0; b < nbands; b++)
+            for (int g = 0; g < RI_GROUPS && g * 64 * RI_WAVES < W; g++) out[1 + n++] = (uint32_t)b | ((uint32_t)g << 8) | (((1u << RI_WAVES) - 1u) << 12);
+    }
+    out[0] = (uint32_t)n;
+    return true;
 }
 
 hipError_t retrack_init()

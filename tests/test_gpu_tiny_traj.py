@@ -12,6 +12,14 @@ import oracle
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 PRINT = 1.1e-3
+# HEAD's keyframe policy against the pictures' (a keyframe on every frame) and the one swapped near-tie of frame 2: what this code's
+# poses differ from the printed ones by, frame by frame - [x m, y m, theta deg], oracle (= engine to 1e-4 m / 1e-5 rad) minus print.
+# Frames 4-5: the nine-way clique tie of frame 4; 6-8: the pair solved against a two-frame-old keyframe; 9-10: the
+# reference's inlier sets differ from ours by one point each (profiles/r06_frame_markers_8_10.txt).  KNOWN differences, pinned to 1.6e-3
+# (1e-3 + the prints' rounding) instead of the blanket 0.15 m / 0.3 deg of rounds 4-5.
+KNOWN_DIFF = {4: (0.016327, 0.026739, -0.029540), 5: (0.016128, 0.024040, -0.028859), 6: (0.019532, -0.061734, 0.095391),
+              7: (0.025198, -0.058284, 0.089876), 8: (0.026503, -0.054397, 0.092879), 9: (-0.010646, -0.050218, 0.192600),
+              10: (-0.082521, -0.068067, 0.238190)}
 
 
 def test_engine_reproduces_the_reference_prints_on_data_tiny():
@@ -19,6 +27,9 @@ def test_engine_reproduces_the_reference_prints_on_data_tiny():
     from radarslampy_amd.engine import Engine
     traj = np.load(os.path.join(HERE, "golden", "tiny_traj.npz"))
     pay = np.load(os.path.join(HERE, "golden", "tiny_track.npz"))["payload"]
+    # the reference's OWN loop code (RawROAMSystem.run at HEAD) run with the oracle's front end - tests/golden/make_tiny_hybrid.py: the
+    # engine against the reference's loop in one hop
+    hybrid = np.load(os.path.join(HERE, "golden", "tiny_hybrid.npz"))["poses_plain_head"]
     T, rows, clip = pay.shape
     det = lambda c: oracle.getFeatures(c)[0]                                    # noqa: E731
     ctx = _ffi.Context(0)
@@ -39,6 +50,7 @@ def test_engine_reproduces_the_reference_prints_on_data_tiny():
         assert (got["n_tracked"], got["n_good"], got["n_inliers"]) == (want["n_tracked"], want["n_good"], want["n_inliers"]), t
         assert got["clique_proven"], t
         assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= 1e-4 and abs(got["pose"][2] - want["pose"][2]) <= 1e-5, t
+        assert np.abs(got["pose"][:2] - hybrid[t][:2]).max() <= 1.2e-4 and abs(got["pose"][2] - hybrid[t][2]) <= 1.2e-5, (t, got["pose"], hybrid[t])
         est.append(np.array(got["pose"]))
         printed = np.array([got["pose"][0], got["pose"][1], np.rad2deg(got["pose"][2])])
         d = np.abs(printed - traj["roam_mapping_est_pose"][t - 1])
@@ -47,7 +59,8 @@ def test_engine_reproduces_the_reference_prints_on_data_tiny():
             assert d.max() <= PRINT, (t, printed, traj["roam_mapping_est_pose"][t - 1])          # the reference's own print
             assert abs(rmse - traj["roam_mapping_rmse"][t - 1]) <= 5.1e-3, t
         else:
-            assert d[:2].max() < 0.15 and d[2] < 0.3, (t, d)                                      # frame 4 on
+            sd = printed - traj["roam_mapping_est_pose"][t - 1]
+            assert np.abs(sd - np.array(KNOWN_DIFF[t])).max() <= 1.6e-3, (t, sd, KNOWN_DIFF[t])       # the known difference, not a blanket
             assert abs(rmse - traj["roam_mapping_rmse"][t - 1]) < 0.02, t
         if got["retrack"]:
             retracks.append(t)

@@ -218,15 +218,26 @@ def test_oracle_loop_equals_the_reference_loop_code(data):
                 assert np.abs(out["pose"][:2] - want[t][:2]).max() <= 2e-5 and abs(out["pose"][2] - want[t][2]) <= 2e-6, (swap, every, t, out["pose"], want[t])
 
 
-def test_frames_6_to_10_stay_in_the_neighbourhood(data):
+# what HEAD's keyframe policy + the un-swapped frame-2 near-tie leave between this code's poses and the printed ones, per frame
+# ([x m, y m, theta deg], ours minus print; frames 1-3 reproduce the prints): KNOWN differences, pinned - the GPU
+# twin tests/test_gpu_tiny_traj.py asserts the same table on the engine
+KNOWN_DIFF = {4: (0.016327, 0.026739, -0.029540), 5: (0.016128, 0.024040, -0.028859), 6: (0.019532, -0.061734, 0.095391),
+              7: (0.025198, -0.058284, 0.089876), 8: (0.026503, -0.054397, 0.092879), 9: (-0.010646, -0.050218, 0.192600),
+              10: (-0.082521, -0.068067, 0.238190)}
+
+
+def test_frames_4_to_10_differ_from_the_prints_by_the_known_amounts(data):
     traj, pay = data
     pipe = _pipeline(traj, pay)
     est = [traj["gt_pose"][0]]
     for t in range(1, 11):
         out = pipe.step(np.ascontiguousarray(pay[t]))
         est.append(out["pose"].copy())
-        d = np.abs(_printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1])
-        assert d[:2].max() < 0.15 and d[2] < 0.3, (t, d)
+        sd = _printed(out["pose"]) - traj["roam_mapping_est_pose"][t - 1]
+        if t >= 4:
+            assert np.abs(sd - np.array(KNOWN_DIFF[t])).max() <= 1.1e-3, (t, sd)
+        else:
+            assert np.abs(sd).max() <= 1.1e-3, (t, sd)
         assert abs(_rmse(traj["gt_pose"][:t + 1], est) - traj["roam_mapping_rmse"][t - 1]) < 0.02, t
     # the retrack frames of the reference's run are the frames whose picture shows the freshly appended features: 1, 2, 4, 7, 9
 
