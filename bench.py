@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the N-core CPU leg (-1 = half the logical cores, 0 = skip)")
     ap.add_argument("--no-md", action="store_true", help="motionDistortion OFF (Kabsch dead reckoning)")
     ap.add_argument("--no-retrack", action="store_true", help="round-1 workload: host-seeded features, no re-detection in the timed loop")
-    ap.add_argument("--retrack-slots", type=int, default=0, help="lanes whose detection scratch is resident at once (0 = min(lanes, 512))")
+    ap.add_argument("--retrack-slots", type=int, default=0, help="lanes whose detection scratch is resident at once (0 = min(lanes, 2048))")
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--h2d", action="store_true", help="stream every scan from pinned host memory over PCIe (double-buffered pool); reports the PCIe-inclusive rate")
     ap.add_argument("--engines", type=int, default=1, help="independent engine instances (contexts/streams) per GPU; lanes are split between them")
@@ -456,7 +456,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             # the number n of lanes that re-detect (only the device knows it); chunk c holds clamp(n - c * slots, 0, slots) detections,
             # and n is in the result records consumed above.  live[k] = mean duration of the busy launches, their detections on average
             # = doh_units_per_launch (the first chunk of a step overlaps the front end of later steps, the others mostly run alone)
-            slots_ = min(B // len(engs), args.retrack_slots or 512)
+            slots_ = min(B // len(engs), args.retrack_slots or 2048)
             nst = min(args.steps, 64)
             n_step = [stat.get("per_step", {}).get(pre + args.warmup + k, 0) for k in range(args.steps - nst, args.steps)]
             # (chunks of fewer than 200 detections take the two-pass integral kernels - three times the traffic of the one-sweep kernel
@@ -681,7 +681,7 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     per_step = {k: iso[k][0] for k in names}                       # ms of the kernel alone per step
     slots = None
     if not args.no_retrack:
-        slots = min(B, args.retrack_slots or 512)
+        slots = min(B, args.retrack_slots or 2048)
         for k in ("doh_integral", "doh_det_maxima"):
             iso[k] = eng.time_kernel(k, max(1, args.kernel_reps // 3))      # one launch = `slots` detections
             per_step[k] = iso[k][0] / slots * retrack_fraction * B

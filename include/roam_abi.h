@@ -195,7 +195,7 @@ typedef struct roam_engine_cfg {
     double sigma5[5];
     int32_t retrack_on_device;/* 1: lanes that run out of features (<= 60 inliers, RawROAMSystem.py:250-271) re-detect
                                  (appendNewFeatures: DoH blobs + ANMS, getFeatures.py:74-118) inside roam_engine_step */
-    int32_t retrack_slots;    /* lanes whose detection scratch (33 MB each) is resident at once; 0 = min(lanes, 512) */
+    int32_t retrack_slots;    /* lanes whose detection scratch (33 MB each) is resident at once; 0 = min(lanes, 2048) */
     /* Map.isGoodKeyframe (Mapping.py:149-174): a keyframe is added when the pose moved this far from the last one.  <= 0: the
      * reference's constants, TRANS_THRESHOLD = 2.0 m and ROT_THRESHOLD = 0.2 rad (Mapping.py:13-15).  (The pictures the reference keeps
      * of its data/tiny run were made with a keyframe on EVERY frame - DESIGN.md section 4; 1e-9 reproduces that.) */

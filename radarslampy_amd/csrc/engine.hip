@@ -665,7 +665,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         r.size1 = (int)(3 * r.sigma1); r.size2 = (int)(3 * r.sigma2);
         r.W = e->W; r.rows = cfg->rows; r.cols = cfg->clip; r.stride = cfg->stride; r.payload_off = cfg->payload_off;
         r.rec_bytes = (int64_t)e->rec_bytes;
-        const int R = r.slots = std::max(1, std::min(B, cfg->retrack_slots > 0 ? cfg->retrack_slots : 512));
+        const int R = r.slots = std::max(1, std::min(B, cfg->retrack_slots > 0 ? cfg->retrack_slots : 2048));      // (round 6: 512 -> 2048, +2.5 % on the default workload)
         const size_t npx = (size_t)e->W * e->W;
         if (e->W > 2048) { ROAM_SET_ERR(ctx, "engine: device retrack needs a Cartesian image of at most 2048 x 2048"); roam_engine_destroy(ctx); return ROAM_E_ARG; }
         ok = ok && dalloc(ctx, e, &r.rt_n, 1) && dalloc(ctx, e, &r.rt_lane, (size_t)B) && dalloc(ctx, e, &r.rt_scan, (size_t)B);

@@ -14,9 +14,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PRINT = 1.1e-3
 # HEAD's keyframe policy against the pictures' (a keyframe on every frame) and the one swapped near-tie of frame 2: what this code's
 # poses differ from the printed ones by, frame by frame - [x m, y m, theta deg], oracle (= engine to 1e-4 m / 1e-5 rad) minus print.
-# Frames 4-5: the nine-way clique tie of frame 4; 6-8: the pair solved against a two-frame-old keyframe; 9-10: the
-# reference's inlier sets differ from ours by one point each (profiles/r06_frame_markers_8_10.txt).  KNOWN differences, pinned to 1.6e-3
-# (1e-3 + the prints' rounding) instead of the blanket 0.15 m / 0.3 deg of rounds 4-5.
+# Frames 4-5: the near-tie of frame 2's detector responses taken in the other order (it renumbers the features: another of frame 4's nine
+# tied cliques); 6-8: the pair solved against a two-frame-old keyframe; 9-10: a second near-tie, at the re-detection of frame 7 (one
+# feature exchanged: profiles/r06_frame_markers_8_10.txt, r06_frame8_swap_search.txt).  With both swaps and the pictures' keyframe policy
+# the oracle prints ALL TEN frames (tests/test_oracle_tiny_traj.py::test_two_swapped_near_ties_reproduce_all_ten_printed_frames); neither
+# can be injected into the engine, so here the KNOWN differences are pinned - to 1.6e-3 (1e-3 + the prints' rounding) instead of the
+# blanket 0.15 m / 0.3 deg of rounds 4-5.
 KNOWN_DIFF = {4: (0.016327, 0.026739, -0.029540), 5: (0.016128, 0.024040, -0.028859), 6: (0.019532, -0.061734, 0.095391),
               7: (0.025198, -0.058284, 0.089876), 8: (0.026503, -0.054397, 0.092879), 9: (-0.010646, -0.050218, 0.192600),
               10: (-0.082521, -0.068067, 0.238190)}
