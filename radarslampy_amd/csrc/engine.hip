@@ -746,12 +746,24 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (e->rt_on && e->W <= 2048) {
         // the phases the one-sweep integral kernel walks: from the sampling map and the dark-step table just made (host code, once)
-        const size_t npx = (size_t)e->W * e->W, ndt = retrack_darktab_words(e->W);
-        std::vector<uint32_t> mh(npx), dh(ndt), ph(retrack_phase_words(e->W), 0u);
-        HIP_TRY(ctx, hipMemcpy(mh.data(), e->warp_map, npx * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(dh.data(), e->rt.darktab, ndt * 4, hipMemcpyDeviceToHost));
-        if (!retrack_build_phases(mh.data(), dh.data(), e->W, cfg->clip, ph.data())) { ROAM_SET_ERR(ctx, "retrack: phase list"); roam_engine_destroy(ctx); return ROAM_E_ARG; }
-        HIP_TRY(ctx, hipMemcpy(const_cast<uint32_t *>(e->rt.phlist), ph.data(), ph.size() * 4, hipMemcpyHostToDevice));
+        // (through PINNED staging: a pageable hipMemcpy of this size leaves the runtime in a state in which the small device-to-device
+        // copy of the keyframe exchange costs 80 us more per step - measured, round 6)
+        const size_t npx = (size_t)e->W * e->W, ndt = retrack_darktab_words(e->W), nph = retrack_phase_words(e->W);
+        uint32_t *stage = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&stage), (npx + ndt + nph) * 4, hipHostMallocDefault));
+        uint32_t *mh = stage, *dh = stage + npx;
+        std::vector<uint32_t> ph(nph, 0u);
+        hipError_t ec = hipMemcpyAsync(mh, e->warp_map, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (ec == hipSuccess) ec = hipMemcpyAsync(dh, e->rt.darktab, ndt * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (ec == hipSuccess) ec = hipStreamSynchronize(ctx->stream);
+        bool okp = ec == hipSuccess && retrack_build_phases(mh, dh, e->W, cfg->clip, ph.data());
+        if (okp) {
+            memcpy(stage + npx + ndt, ph.data(), nph * 4);
+            ec = hipMemcpyAsync(const_cast<uint32_t *>(e->rt.phlist), stage + npx + ndt, nph * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (ec == hipSuccess) ec = hipStreamSynchronize(ctx->stream);
+        }
+        (void)hipHostFree(stage);
+        if (!okp || ec != hipSuccess) { ROAM_SET_ERR(ctx, "retrack: phase list (%s)", ec != hipSuccess ? hipGetErrorString(ec) : "image too large"); roam_engine_destroy(ctx); return ec != hipSuccess ? ROAM_E_HIP : ROAM_E_ARG; }
         for (uint32_t i = 0; i < ph[0]; i++) {
             const int band = (int)(ph[1 + i] & 255u), g = (int)((ph[1 + i] >> 8) & 15u), hrows = std::min(16, e->W - 16 * band);
             for (int w = 0; w < 4; w++)
