@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 struct __attribute__((packed)) RtU16 { uint16_t v; };
 struct __attribute__((packed)) RtU32 { uint32_t v; };
 #ifndef RI_BOX
-#define RI_BOX 1536
+#define RI_BOX 2560                         // (round 6: 1536 -> 2560, the LDS that is left at two workgroups per CU: fewer patches on the gather path, -2 %)
 #endif
 #ifndef RI_PREFETCH
 #define RI_PREFETCH 1                       // the box of the next phase is loaded one phase ahead (rt_integral_kernel)
