@@ -117,6 +117,10 @@ struct Engine {
     hipEvent_t tr_ev[64][6] = {};
     hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
+    hipEvent_t ev_int = nullptr;                    // after the integral images of a step's (first) detection chunk
+    bool ev_int_valid = false;
+    int warp_after_int = 0;                         // ROAM_WARP_AFTER_INTEGRAL (experiment)
+    int pyr_after_int = 0;                          // ROAM_PYR_AFTER_INTEGRAL: the next pyramid waits for it (experiment, round 6)
     int64_t rt_image_px = 0;                        // pixels of the integral image that are written and read (the needed tiles of the phase list)
     bool tr_ev_ok[64] = {};                          // the step recorded its front-end event pairs (stage events were on when it was enqueued)
     int64_t stage_ev_step = -1;                     // the step whose ev[] (back-end stage events) are valid, -1: none
@@ -687,6 +691,16 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             // asked for: by the environment here, by roam_engine_debug_detect / roam_engine_time_kernel("doh_fused") on first use)
             const char *fv = getenv("ROAM_FUSED_DETECT");
             r.fused = (fv && fv[0] == '1') ? 1 : 0;
+            // Where the pyramid of the step after next runs (round 6).  Left alone it starts when its warp ends - beside the integral images
+            // of this step, the one pairing on this path that is WORSE than running the two one after the other (integral 31 ms + pyramid
+            // 15.5 ms in-step against 25 + 6.3 alone).  2: it waits for this step's determinants (1: for the integral images) and runs
+            // beside the next step's back end: +2 % on the default workload.  Batches only - a single sequence lives on the overlap of
+            // its front end with the previous pair's back end.  ROAM_PYR_AFTER_INTEGRAL = 0 / 1 / 2 overrides.
+            const char *pv = getenv("ROAM_PYR_AFTER_INTEGRAL");
+            e->pyr_after_int = pv ? atoi(pv) : (B >= 256 ? 2 : 0);
+            const char *wv = getenv("ROAM_WARP_AFTER_INTEGRAL");
+            e->warp_after_int = wv ? atoi(wv) : 0;
+            if (e->warp_after_int && !e->pyr_after_int) e->pyr_after_int = 1;     // (the event is made for either)
             r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
         }
         // candidate lists and bookkeeping tables per DETECTION (0.9 MB each): K4-K7 run once per step over all of them
@@ -1302,11 +1316,13 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev_pk1, sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[5], sP));
     HIP_TRY(ctx, hipEventRecord(e->ev_peaks, sP));
+    if (e->warp_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[1], sA));
     HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride, e->warp_dark_zero));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[2], sA));
     HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
     HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
+    if (e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[3], sB));
     HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B, e->pyr_dark));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[4], sB));
@@ -1363,7 +1379,9 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
         e->rt.res = res_slot;
         HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS));
+        if (e->pyr_after_int && !e->ev_int) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_int, hipEventDisableTiming));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int == 2));
+        if (e->pyr_after_int) e->ev_int_valid = true;
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }
     e->rt_ev_ok[e->nstep & 63] = e->rt_on && e->rt_mode && e->stage_ev;

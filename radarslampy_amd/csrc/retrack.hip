@@ -1899,7 +1899,7 @@ static hipError_t launch_det(hipStream_t st, const RtArgs &a, int first, int P)
     return hipGetLastError();
 }
 
-hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace)
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace, hipEvent_t after_integral, int after_det)
 {
     const int W = a.W, R = a.slots;
     // image-scale kernels chunk by chunk (the float64 integral images of `slots` detections are resident at once); the
@@ -1923,7 +1923,9 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, first);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
+        if (after_integral && !after_det && first == 0 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;      // (the pyramid of a later step may wait for it)
         if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
+        if (after_integral && after_det && first + R >= B && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[2], st)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
