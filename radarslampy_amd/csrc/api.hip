@@ -22,7 +22,15 @@ int32_t roam_create(int32_t device_id, roam_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
     ctx->cu_count = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
+    {
+        // ROAM_MAIN_PRIORITY=1 (experiment, round 6): the main stream - back end and detection, the critical path of a step - above the
+        // front-end streams in the hardware queues
+        const char *pv = getenv("ROAM_MAIN_PRIORITY");
+        int lo = 0, hi = 0;
+        if (pv && pv[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+            if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
+        } else if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return ROAM_E_HIP; }
+    }
     // front-end stream: peaks, warp and pyramid of a step run here so that they can overlap the back end
     // (KLT ... LM) of the previous step; equal priority measured best once the two stages are pipelined
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return ROAM_E_HIP; }

@@ -120,6 +120,7 @@ struct Engine {
     hipEvent_t ev_int = nullptr;                    // after the integral images of a step's (first) detection chunk
     bool ev_int_valid = false;
     int warp_after_int = 0;                         // ROAM_WARP_AFTER_INTEGRAL (experiment)
+    int peaks_after_int = 0;                        // ROAM_PEAKS_AFTER_INTEGRAL (experiment): the peak kernel waits for the same event as the pyramid
     int pyr_after_int = 0;                          // ROAM_PYR_AFTER_INTEGRAL: the next pyramid waits for it (experiment, round 6)
     int64_t rt_image_px = 0;                        // pixels of the integral image that are written and read (the needed tiles of the phase list)
     bool tr_ev_ok[64] = {};                          // the step recorded its front-end event pairs (stage events were on when it was enqueued)
@@ -698,6 +699,10 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             // its front end with the previous pair's back end.  ROAM_PYR_AFTER_INTEGRAL = 0 / 1 / 2 overrides.
             const char *pv = getenv("ROAM_PYR_AFTER_INTEGRAL");
             e->pyr_after_int = pv ? atoi(pv) : (B >= 256 ? 2 : 0);
+            // the polar peaks of the step after next (needed by that step's keyframe glue only) wait for the same event: they run beside the
+            // one-wavefront-per-detection bookkeeping that ends this step instead of beside its back end: +2 % more (50.8 -> 51.8 k)
+            const char *kv = getenv("ROAM_PEAKS_AFTER_INTEGRAL");
+            e->peaks_after_int = kv ? atoi(kv) : (B >= 256 ? 1 : 0);
             const char *wv = getenv("ROAM_WARP_AFTER_INTEGRAL");
             e->warp_after_int = wv ? atoi(wv) : 0;
             if (e->warp_after_int && !e->pyr_after_int) e->pyr_after_int = 1;     // (the event is made for either)
@@ -1308,6 +1313,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipStream_t sP = ctx->stream5;
     HIP_TRY(ctx, hipEventRecord(e->ev_idx, sA));
     HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_idx, 0));
+    if (e->peaks_after_int && e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[0], sP));
@@ -1380,7 +1386,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         e->rt.res = res_slot;
         HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
         if (e->pyr_after_int && !e->ev_int) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_int, hipEventDisableTiming));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int == 2));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1));
         if (e->pyr_after_int) e->ev_int_valid = true;
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }

@@ -1925,7 +1925,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
         if (after_integral && !after_det && first == 0 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;      // (the pyramid of a later step may wait for it)
         if ((e = launch_det(st, a, first, P)) != hipSuccess) return e;
-        if (after_integral && after_det && first + R >= B && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;
+        if (after_integral && after_det == 1 && first + R >= B && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[2], st)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
@@ -1942,6 +1942,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
     e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rt_append_kernel, dim3(B), dim3(256), 0, st, a, 0);
+    if (after_integral && after_det == 2 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;     // (after the whole chain)
     return hipGetLastError();
 }
 
