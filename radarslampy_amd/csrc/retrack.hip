@@ -76,58 +76,77 @@ __device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dm
 #define RI_MIN_DETECTIONS RT_TWO_PASS_SLOTS
 __device__ __forceinline__ bool rt_one_sweep(const RtArgs &a, int first) { return a.W <= 2048 && *a.rt_n - first >= RI_MIN_DETECTIONS; }
 
+struct __attribute__((packed)) RtU16 { uint16_t v; };
+struct __attribute__((packed)) RtU32 { uint32_t v; };
+// one Cartesian pixel out of the polar record (the arithmetic of warp_gather_kernel's direct path = warp_pixel); lut[k] = rt_code_to_f32(k)
+__device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict__ p, int rows, int cols, int stride, const float *lut)
+{
+    const int ix = m & 4095, iy = (m >> 12) & 1023;
+    if (ix >= cols) return 0.f;
+    const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
+    const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
+    int r0 = iy - 1, r1 = iy;
+    if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
+    if (r1 >= rows) r1 -= rows;
+    const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
+    const bool i1 = ix + 1 < cols;
+    // in the last column the pair is read one byte to the left and shifted, so that no load leaves the row
+    const int back = i1 ? 0 : 1, sh = back * 8;
+    const uint32_t w0 = reinterpret_cast<const RtU16 *>(q0 - back)->v >> sh, w1 = reinterpret_cast<const RtU16 *>(q1 - back)->v >> sh;
+    const float s00 = lut[w0 & 255], s01 = i1 ? lut[w0 >> 8] : 0.f;        // lut[k] = rt_code_to_f32(k)
+    const float s10 = lut[w1 & 255], s11 = i1 ? lut[w1 >> 8] : 0.f;
+    float v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
+    v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
+    v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
+    v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
+    return v;
+}
+
 // Column pass, parallel over bands of RC_BAND rows.  A pixel is a float32 of at least 2^-18 (code / 255 times a weight product that is a
 // multiple of 2^-10) or zero, i.e. a multiple of 2^-41, and a column of at most 4094 of them sums to less than 2^12: every partial
-// sum is EXACT in float64, in any order.  So a thread adds up its column inside one band only (a chain of 64 instead of 2024 rows:
-// this pass was 1.0 of the 2.8 ms of a lone detection), writes the band-local sums and the band's total; rt_integ_colfix_kernel
-// turns the totals into what lies above each band, and the row pass adds that in as it loads (all exact = NumPy's values).
+// sum is EXACT in float64, in any order.  So the 64 rows of a band's column are four threads of 16 rows each (round 6; one thread per
+// band column until then: 16 dependent pairs of round trips - map word, then taps - were 48 of a lone detection's 54 us in this pass):
+// all 16 map words leave at once, then all 64 taps, the quarters' totals meet in LDS; the workgroup writes the band-local sums and the
+// band's total; rt_integ_colfix_kernel turns the totals into what lies above each band, and the row pass adds that in as it loads (all
+// exact = NumPy's values).
 #define RC_BAND 64
+#define RC_Q 16                              // rows per thread: RC_BAND / 4
 __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 {
     const int ls = blockIdx.z, slot = first + ls;
     if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
-    const int c = blockIdx.x * 256 + threadIdx.x, W = a.W, band = blockIdx.y, nb = (W + RC_BAND - 1) / RC_BAND;
-    if (c >= W) return;
+    __shared__ double tot[4][64];
+    __shared__ float lut[256];
+    lut[threadIdx.x] = rt_code_to_f32(threadIdx.x);
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, W = a.W, band = blockIdx.y, nb = (W + RC_BAND - 1) / RC_BAND;
     const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
     double *S = a.S + (int64_t)ls * a.SP * W;
     const int rows = a.rows, cols = a.cols, stride = a.stride;
-    double acc = 0;
-    auto pixel = [&](uint32_t m) -> float {              // the arithmetic of warp_gather_kernel's direct path (= warp_pixel)
-        const int ix = m & 4095, iy = (m >> 12) & 1023;
-        if (ix >= cols) return 0.f;
-        const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
-        const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
-        int r0 = iy - 1, r1 = iy;
-        if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
-        if (r1 >= rows) r1 -= rows;
-        const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
-        const bool i1 = ix + 1 < cols;
-        const float s00 = rt_code_to_f32(q0[0]), s01 = i1 ? rt_code_to_f32(q0[1]) : 0.f;
-        const float s10 = rt_code_to_f32(q1[0]), s11 = i1 ? rt_code_to_f32(q1[1]) : 0.f;
-        float v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
-        v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
-        v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
-        v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
-        return v;
-    };
-    // four rows per iteration: their map words and taps are independent loads, only the four additions are a chain
-    int r = band * RC_BAND;
-    const int rend = min(r + RC_BAND, W);
-    for (; r + 4 <= rend; r += 4) {
-        uint32_t m[4];
+    const int r0 = band * RC_BAND + q * RC_Q;
+    uint32_t m[RC_Q];
 #pragma unroll
-        for (int k = 0; k < 4; k++) m[k] = a.map[(int64_t)(r + k) * W + c];
-        float v[4];
+    for (int k = 0; k < RC_Q; k++) m[k] = (c < W && r0 + k < W) ? a.map[(int64_t)(r0 + k) * W + c] : 0xfffu;     // (bin 4095: beyond any scan, a zero pixel)
+    __syncthreads();                                   // (the table; the map words are on their way)
+    float v[RC_Q];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = pixel(m[k]);
+    for (int k = 0; k < RC_Q; k++) v[k] = rt_pixel(m[k], p, rows, cols, stride, lut);      // (= warp_pixel: two 16-bit loads, table decode)
+    double s[RC_Q], acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { acc = __dadd_rn(acc, (double)v[k]); S[(int64_t)(r + k) * a.SP + c] = acc; }
-    }
-    for (; r < rend; r++) { acc = __dadd_rn(acc, (double)pixel(a.map[(int64_t)r * W + c])); S[(int64_t)r * a.SP + c] = acc; }
-    a.colT[((int64_t)ls * nb + band) * W + c] = acc;
+    for (int k = 0; k < RC_Q; k++) { acc = __dadd_rn(acc, (double)v[k]); s[k] = acc; }
+    tot[q][lane] = acc;
+    __syncthreads();
+    double base = 0;
+    for (int j = 0; j < q; j++) base = __dadd_rn(base, tot[j][lane]);
+    if (c >= W) return;
+#pragma unroll
+    for (int k = 0; k < RC_Q; k++)
+        if (r0 + k < W) S[(int64_t)(r0 + k) * a.SP + c] = __dadd_rn(base, s[k]);
+    if (q == 3) a.colT[((int64_t)ls * nb + band) * W + c] = __dadd_rn(base, acc);
 }
 
-// band totals -> sum of the bands above (exclusive prefix per column; exact, see above)
+// band totals -> sum of the bands above (exclusive prefix per column; exact, see above); the totals are loaded 32 at a time (one round
+// trip instead of one per band: the store of band b kept the compiler from moving the load of band b + 1 above it - 11 us alone)
 __global__ __launch_bounds__(256) void rt_integ_colfix_kernel(RtArgs a, int first)
 {
     const int ls = blockIdx.y, slot = first + ls;
@@ -136,57 +155,112 @@ __global__ __launch_bounds__(256) void rt_integ_colfix_kernel(RtArgs a, int firs
     if (c >= W) return;
     double *T = a.colT + (int64_t)ls * nb * W + c;
     double run = 0.0;
-    for (int b = 0; b < nb; b++) { const double t = T[(int64_t)b * W]; T[(int64_t)b * W] = run; run = __dadd_rn(run, t); }
+    for (int b0 = 0; b0 < nb; b0 += 32) {
+        double tv[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) tv[j] = b0 + j < nb ? T[(int64_t)(b0 + j) * W] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; j++)
+            if (b0 + j < nb) { T[(int64_t)(b0 + j) * W] = run; run = __dadd_rn(run, tv[j]); }
+    }
 }
 
-// one wavefront per 64 rows: lane = row, sequential along the row (the reference's summation order); the image streams
-// through LDS in 64 x RT_CW tiles so that global accesses stay coalesced (a lane of the load covers RT_CW / 16 rows x 16 B)
-#ifndef RT_CW
-#define RT_CW 32
-#endif
-__global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
+// Row pass: a workgroup per 16 rows; 16 lanes of wave 0, lane = row, walk sequentially along the row (the reference's summation order);
+// the image streams through LDS in 16 x 256 tiles so that global accesses stay coalesced (all four waves load and store, 2 KB per row).
+// Round 6, for the lone detection of a single sequence (197 us until then, for a chain of 2 024 additions):
+//   * the tiles of the next RR_DEPTH steps are in flight in registers (the loads of tile i + 1 used to leave one 32-column chain ahead
+//     of their use: 64 tiles x one HBM round trip);
+//   * 16 rows per workgroup instead of 64: 127 workgroups instead of 32 - a CU moves ~36 GB/s of this pattern, and 32 of them needed
+//     57 us for the 65 MB whatever the chain cost (ablation: profiles/r06_detection_experiments.txt);
+//   * the next 16 values of the chain are read from LDS while the current 16 are added.
+#define RR_DEPTH 4
+#define RR_ROWS 16
+#define RR_COLS 256
+__global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
 {
-    static_assert(RC_BAND == 64, "a workgroup of this kernel is one band of the column pass");
-    __shared__ double tile[64][RT_CW + 1];
+    static_assert(RC_BAND % RR_ROWS == 0, "the rows of a workgroup lie in one band of the column pass");
+    // (one buffer: a thread stores, and then overwrites, its own elements only; a row pitch of 258 doubles: every access below is a 16-byte one,
+    // and the 16 chain lanes - 4 banks each, 4 apart - cover the 64 banks exactly)
+    __shared__ __align__(16) double tile[RR_ROWS][RR_COLS + 2];
     const int ls = blockIdx.y, slot = first + ls;
     if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
     const int W = a.W, H = a.W, nb = (W + RC_BAND - 1) / RC_BAND;
-    double *S = a.S + (int64_t)ls * a.SP * W;
-    const double *T = a.colT + ((int64_t)ls * nb + blockIdx.x) * W;   // column sums of the bands above this one
-    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
-    constexpr int RPI = 64 / RT_CW;                     // rows per load instruction
-    constexpr int NLD = 64 / RPI;                       // loads per lane and tile
-    const int lr = lane / RT_CW, lc = lane % RT_CW;
-    double acc = 0;
-    // the next tile's loads are in flight while this tile's chain runs (a lone detection waited for 64 round trips to HBM here)
-    double nxt[NLD], off = 0.0, offn = 0.0;
-    auto fetch = [&](int c0) {
-        const int c = c0 + lc;
-        offn = c < W ? T[c] : 0.0;
+    double *S = a.S + (int64_t)ls * a.SP * W;          // (rows are 128-byte aligned: SP is a multiple of 16)
+    const int r0 = blockIdx.x * RR_ROWS;
+    const double *T = a.colT + ((int64_t)ls * nb + r0 / RC_BAND) * W;     // column sums of the bands above this one
+    // a lane moves PAIRS of columns (16-byte loads and stores: 18 memory instructions per tile and lane, so that RR_DEPTH - 1 tiles in
+    // flight stay below the 64 a wave can have outstanding): 128 lanes per row, 2 rows per instruction of the workgroup
+    const int lc = 2 * (threadIdx.x & 127), lr = threadIdx.x >> 7;
+    const int ntiles = (W + RR_COLS - 1) / RR_COLS;
+    double2 reg[RR_DEPTH][8], off[RR_DEPTH];
+    // (loads are unconditional, from clamped addresses, and what lies outside the image is zeroed when the tile is USED: a conditional load
+    // is a branch whose join waits for the data - the prefetch would be gone)
+    const int ce = (W - 1) & ~1;                                          // the last even column: ce + 1 < SP
+    auto fetch = [&](double2 (&x)[8], double2 &o, int i) {
+        const int c = i * RR_COLS + lc;
+        o.x = T[min(c, W - 1)];
+        o.y = T[min(c + 1, W - 1)];
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int r = r0 + k * RPI + lr;
-            nxt[k] = (r < H && c < W) ? S[(int64_t)r * a.SP + c] : 0.0;
-        }
+        for (int k = 0; k < 8; k++) x[k] = *reinterpret_cast<const double2 *>(S + (int64_t)min(r0 + 2 * k + lr, H - 1) * a.SP + min(c, ce));
     };
-    fetch(0);
-    for (int c0 = 0; c0 < W; c0 += RT_CW) {
-        const int c = c0 + lc;
-        off = offn;
 #pragma unroll
-        for (int k = 0; k < NLD; k++) tile[k * RPI + lr][lc] = __dadd_rn(nxt[k], off);
-        __syncthreads();
-        if (c0 + RT_CW < W) fetch(c0 + RT_CW);
-        const int nc = min(RT_CW, W - c0);
-        for (int j = 0; j < nc; j++) { acc = __dadd_rn(acc, tile[lane][j]); tile[lane][j] = acc; }
-        __syncthreads();
+    for (int d = 0; d < RR_DEPTH; d++) fetch(reg[d], off[d], min(d, ntiles - 1));
+    double acc = 0;
+    // tile i out of its registers, the tile RR_DEPTH steps later into them.  Nothing between two uses of a register set is conditional:
+    // the compiler's wait for "these loads" counts the memory instructions that are CERTAIN to have followed them - behind `if`s, none
+    auto step = [&](double2 (&x)[8], double2 &o, int i) {
+        const int c = i * RR_COLS + lc;
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
-            const int r = r0 + k * RPI + lr;
-            if (r < H && c < W) S[(int64_t)r * a.SP + c] = tile[k * RPI + lr][lc];
+        for (int k = 0; k < 8; k++) {
+            const bool rin = r0 + 2 * k + lr < H;
+            *reinterpret_cast<double2 *>(&tile[2 * k + lr][lc]) =
+                make_double2(rin && c < W ? __dadd_rn(x[k].x, o.x) : 0.0, rin && c + 1 < W ? __dadd_rn(x[k].y, o.y) : 0.0);
         }
+        fetch(x, o, min(i + RR_DEPTH, ntiles - 1));                       // (past the end: the last tile again, never used)
         __syncthreads();
+#ifndef RR_NOCHAIN
+        if (threadIdx.x < RR_ROWS) {
+            // (columns past the image hold zeros: the chain runs through them, nothing of it is stored)
+            double2 *row = reinterpret_cast<double2 *>(tile[threadIdx.x]);
+            double2 y[8], z[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) y[j] = row[j];
+            for (int j0 = 0; j0 < RR_COLS / 2; j0 += 16) {                // (two chunks of 16 columns per turn: y and z swap roles, no copies)
+#pragma unroll
+                for (int j = 0; j < 8; j++) z[j] = row[j0 + 8 + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { acc = __dadd_rn(acc, y[j].x); y[j].x = acc; acc = __dadd_rn(acc, y[j].y); y[j].y = acc; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) row[j0 + j] = y[j];
+                const int jn = min(j0 + 16, RR_COLS / 2 - 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) y[j] = row[jn + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { acc = __dadd_rn(acc, z[j].x); z[j].x = acc; acc = __dadd_rn(acc, z[j].y); z[j].y = acc; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) row[j0 + 8 + j] = z[j];
+            }
+        }
+#endif
+        __syncthreads();
+#ifndef RR_NOSTORE
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int r = r0 + 2 * k + lr;
+            const double2 t2 = *reinterpret_cast<const double2 *>(&tile[2 * k + lr][lc]);
+            if (r < H && c + 1 < W) *reinterpret_cast<double2 *>(S + (int64_t)r * a.SP + c) = t2;
+            else if (r < H && c < W) S[(int64_t)r * a.SP + c] = t2.x;
+        }
+#endif
+    };
+    int i0 = 0;
+    for (; i0 + RR_DEPTH <= ntiles; i0 += RR_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < RR_DEPTH; d++) step(reg[d], off[d], i0 + d);
     }
+#pragma unroll
+    for (int d = 0; d < RR_DEPTH - 1; d++)
+        if (i0 + d < ntiles) step(reg[d], off[d], i0 + d);
 }
 
 // ------------------------------------------------------------------------------------------------ K1+K2 fused: one sweep
@@ -219,8 +293,6 @@ __global__ __launch_bounds__(64) void rt_integ_rows_kernel(RtArgs a, int first)
 #endif
 #define RI_PHL_MAX 1024                     // phases of the largest image of the one-sweep kernel (128 bands x 8 groups)
 #define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
-struct __attribute__((packed)) RtU16 { uint16_t v; };
-struct __attribute__((packed)) RtU32 { uint32_t v; };
 #ifndef RI_BOX
 #define RI_BOX 2560                         // (round 6: 1536 -> 2560, the LDS that is left at two workgroups per CU: fewer patches on the gather path, -2 %)
 #endif
@@ -228,29 +300,6 @@ struct __attribute__((packed)) RtU32 { uint32_t v; };
 #define RI_PREFETCH 1                       // the box of the next phase is loaded one phase ahead (rt_integral_kernel)
 #endif
 //                        // bytes of polar footprint a column wave may stage (rt_integral_kernel)                      // two neighbouring codes in one (unaligned) load
-__device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict__ p, int rows, int cols, int stride, const float *lut)
-{
-    const int ix = m & 4095, iy = (m >> 12) & 1023;
-    if (ix >= cols) return 0.f;
-    const float wx1 = __fmul_rn((float)((m >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
-    const float wy1 = __fmul_rn((float)(m >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
-    int r0 = iy - 1, r1 = iy;
-    if (r0 < 0) r0 += rows; else if (r0 >= rows) r0 -= rows;
-    if (r1 >= rows) r1 -= rows;
-    const uint8_t *q0 = p + r0 * stride + ix, *q1 = p + r1 * stride + ix;
-    const bool i1 = ix + 1 < cols;
-    // in the last column the pair is read one byte to the left and shifted, so that no load leaves the row
-    const int back = i1 ? 0 : 1, sh = back * 8;
-    const uint32_t w0 = reinterpret_cast<const RtU16 *>(q0 - back)->v >> sh, w1 = reinterpret_cast<const RtU16 *>(q1 - back)->v >> sh;
-    const float s00 = lut[w0 & 255], s01 = i1 ? lut[w0 >> 8] : 0.f;        // lut[k] = rt_code_to_f32(k)
-    const float s10 = lut[w1 & 255], s11 = i1 ? lut[w1 >> 8] : 0.f;
-    float v = __fmul_rn(s00, __fmul_rn(wy0, wx0));
-    v = __fadd_rn(v, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
-    v = __fadd_rn(v, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
-    v = __fadd_rn(v, __fmul_rn(s11, __fmul_rn(wy1, wx1)));
-    return v;
-}
-
 // the polar footprint of every (band, group, wave) patch of the sweep depends on the sampling map only: computed once per engine
 // (one wave per patch, the reduction the integral kernel used to redo for every detection and phase: 24 cross-lane exchanges)
 __global__ __launch_bounds__(64) void rt_boxtab_kernel(const uint32_t *__restrict__ map, int W, int cols, uint32_t *__restrict__ boxtab)
@@ -1918,9 +1967,9 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if ((e = hipGetLastError()) != hipSuccess) return e;              // (a refused launch - LDS attribute, grid - surfaces here, not after the chain)
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, first);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, first);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
         if (after_integral && !after_det && first == 0 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;      // (the pyramid of a later step may wait for it)
@@ -1973,9 +2022,9 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a_in, int P, int wh
     if (which == 0) {
         hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 255) / 256, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, 0);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + 63) / 64, P2), dim3(64), 0, st, a, 0);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, 0);
     } else {
         return launch_det(st, a, 0, P);                                     // (the caller clears the candidate counts: no bookkeeping follows that would)
     }
