@@ -363,6 +363,8 @@ __device__ void lmpar6(int m, double *a, const int *ipvt, const double *diag, co
     }
 }
 
+#include "lm_wave.inc"
+
 #define LM_LDS_BYTES 65536
 
 // 3 wavefronts per SIMD (<= 168 VGPRs, a few values spill): alone the solve is 15 % slower than at 219 VGPRs, but in
@@ -372,13 +374,14 @@ __device__ void lmpar6(int m, double *a, const int *ipvt, const double *diag, co
 __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
                                                       double *__restrict__ out6, int32_t *__restrict__ nfev_out,
                                                       int32_t *__restrict__ info_out, double *__restrict__ x0_out,
-                                                      double *__restrict__ r0_out, int lds_bytes)
+                                                      double *__restrict__ r0_out, int lds_bytes, int wave_rows)
 {
     extern __shared__ __align__(16) unsigned char lm_smem[];
     __shared__ LmShared S;
     const int b = blockIdx.x, t = threadIdx.x;
     const int N = P.count ? min(P.count[b], P.nmax) : P.N;
     const int m = 2 * N + 3, n = 6;
+    if (N + 2 <= wave_rows) return;                   // mds_lm_wave_kernel's problem (launch_mds_solve)
     if (N < 2) {                                      // lmdif needs m >= n; the caller keeps the previous pose
         if (t == 0) { nfev_out[b] = 0; info_out[b] = -1; for (int j = 0; j < 6; j++) out6[(size_t)b * 6 + j] = 0.0; }
         return;
@@ -432,6 +435,12 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
         __syncthreads();
     }
     const double eps = sqrt(EPSMCH);            // epsfcn = EPS -> sqrt(max(epsfcn, epsmch))
+#ifdef LM_TIMING
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime(), tn;
+#define LM_TICK(k) { tn = __builtin_amdgcn_s_memtime(); tk[k] += tn - tl; tl = tn; }
+#else
+#define LM_TICK(k)
+#endif
 
     for (;;) {   // ------------------------------------------------ outer loop
         // forward-difference Jacobian; rows are owned by fixed threads (no barrier needed
@@ -446,8 +455,10 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
             hh[j] = h;
             xp[j] = xl[j] + h;
         }
+        LM_TICK(0)
         mds_jac(&S, xl, xp, hh, p_w, p_jt, dT, fvec, a, m);
         __syncthreads();
+        LM_TICK(1)
         // ---- qrfac with column pivoting
         for (int j = 0; j < n; j++) {
             double s = 0;
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
             if (t == 0) S.wa1[j] = -ajnorm;
             __syncthreads();
         }
+        LM_TICK(2)
         if (t == 0 && S.iter == 1) {
             for (int j = 0; j < n; j++) S.tmp[j] = S.diag[j] * S.x[j];
             S.xnorm = enorm6(S.tmp);
@@ -552,6 +564,7 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
             if (gnorm <= 1e-8) S.info = 4;
         }
         __syncthreads();
+        LM_TICK(3)
         if (S.info != 0) break;
         for (;;) {   // -------------------------------------------- inner loop
             if (t == 0) {
@@ -565,6 +578,7 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
                 if (S.iter == 1 && S.pnorm < S.delta) S.delta = S.pnorm;
             }
             __syncthreads();
+            LM_TICK(4)
 #pragma unroll
             for (int j = 0; j < 6; j++) xl[j] = S.xtry[j];
             mds_resid(&S, xl, p_w, p_jt, dT, wa4);
@@ -627,10 +641,14 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
             const int info = S.info;
             const double ratio = S.ratio;
             __syncthreads();
+            LM_TICK(5)
             if (info != 0 || !(ratio < 1e-4)) break;
         }
         if (S.info != 0) break;
     }
+#ifdef LM_TIMING
+    if (x0_out && t == 0) for (int k = 0; k < 6; k++) x0_out[(size_t)b * 6 + k] = (double)tk[k];
+#endif
     if (t < 6) out6[(size_t)b * 6 + t] = S.x[t];
     if (t == 0) { nfev_out[b] = S.nfev; info_out[b] = S.info; }
 }
@@ -639,6 +657,23 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
                             int32_t *nfev, int32_t *info, double *x0_out, double *r0_out)
 {
     if (p.B <= 0) return hipSuccess;
+    // problems of up to 254 points: one wavefront each, everything in registers (lm_wave.inc); larger ones: the workgroup form below.
+    // Only the device knows a problem's size, so both kernels are launched when the host-side bound allows both, and each returns
+    // at once from the other's problems.  ROAM_LM_BLOCK=1 keeps the workgroup form for everything (A/B).
+    static const bool block_form = getenv("ROAM_LM_BLOCK") != nullptr && atoi(getenv("ROAM_LM_BLOCK")) != 0;
+    int wave_rows = 0;                                // N + 2 <= wave_rows: the wave kernel's
+    if (!block_form) {
+        const int ppt = std::min(4, (p.nmax + 2 + 63) / 64);
+        wave_rows = 64 * ppt;
+        switch (ppt) {
+        case 1: hipLaunchKernelGGL(mds_lm_wave_kernel<1>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
+        case 2: hipLaunchKernelGGL(mds_lm_wave_kernel<2>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
+        case 3: hipLaunchKernelGGL(mds_lm_wave_kernel<3>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
+        default: hipLaunchKernelGGL(mds_lm_wave_kernel<4>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || p.nmax + 2 <= wave_rows) return e;
+    }
     const size_t mmax = 2 * (size_t)p.nmax + 3;
     size_t need = (mmax * 9 + p.nmax) * sizeof(double);
     // LDS per workgroup caps how many solves a CU runs concurrently, and the solve is latency-bound:
@@ -648,7 +683,7 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     // the solve is a long chain of short reductions: with few points a single wavefront per problem
     // (workgroup barriers degenerate to no-ops, reductions stay in registers) has the lowest latency
     const int threads = p.nmax <= 192 ? 64 : (p.nmax <= 448 ? 128 : LM_TMAX);
-    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds);
+    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds, wave_rows);
     return hipGetLastError();
 }
 

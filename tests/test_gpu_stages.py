@@ -333,6 +333,25 @@ def test_mds_large_problem_global_workspace(ctx):
     assert np.abs(sol[3:5] - want[3:5]).max() <= POS_TOL and abs(sol[5] - want[5]) <= ANG_TOL
 
 
+def test_mds_both_kernel_forms_around_the_switch(ctx):
+    """up to 254 points a problem is one wavefront with its working set in registers (csrc/lm_wave.inc), above that the workgroup form
+    (mds_lm_kernel); both are launched when the bound allows both and each skips the other's problems - sizes on both sides of the switch
+    and at the slot boundaries of the wave form (62 / 63, 126 / 127, 190 / 191 points + the two virtual ones)"""
+    from gen_inputs import mds_problem
+    sigma5 = np.array([4, 4, 1, 1, (5 * np.pi / 180) ** 2], np.float64)
+    for N in (2, 3, 7, 61, 62, 63, 64, 126, 127, 190, 191, 253, 254, 255, 256, 300):
+        T0, p_w, p_jt, Tinit, truth = mds_problem(N, 100 + N, 0.05)
+        sol, nfev, info, x0, r0 = ctx.mds_solve(T0, p_w, p_jt, Tinit, sigma5, want_debug=True)
+        M = oracle.MotionDistortionSolver(np.diag([4, 4]), np.diag([1, 1, (5 * np.pi / 180) ** 2]))
+        M.update_problem(T0, p_w, p_jt, Tinit)
+        want, x0w, r0w = M._solve()
+        assert np.allclose(x0, x0w, rtol=1e-12, atol=1e-12), N
+        assert np.allclose(r0, r0w, rtol=1e-9, atol=1e-11), N                        # the initial residual, every row in MINPACK's order
+        assert 1 <= info <= 4, (N, info)
+        assert np.abs(sol[3:5] - want[3:5]).max() <= POS_TOL and abs(sol[5] - want[5]) <= ANG_TOL, (N, sol, want)
+        assert np.abs(sol[:3] - want[:3]).max() <= 1e-3, (N, sol, want)
+
+
 # ------------------------------------------------------------------ a5 SSC
 def test_ssc(ctx, golden):
     g = golden("ssc")
