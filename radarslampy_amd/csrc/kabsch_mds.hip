@@ -665,11 +665,18 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     if (!block_form) {
         const int ppt = std::min(4, (p.nmax + 2 + 63) / 64);
         wave_rows = 64 * ppt;
+        // register budget: two wavefronts per SIMD (<= 256 registers; the solve wants ~290).  4 096 solves alone: 1.46-1.93 ms against
+        // 1.93-2.51 unconstrained (one wave per SIMD), 1.9-2.4 at three, 2.1-2.7 at four, 3.56-4.48 for the workgroup form; a lone
+        // solve is as fast either way (profiles/r06_lm_experiments.txt).  ROAM_LM_WPE=1: unconstrained (A/B)
+        static const int wpe_env = getenv("ROAM_LM_WPE") ? atoi(getenv("ROAM_LM_WPE")) : 0;
+        const int wpe = wpe_env == 1 ? 1 : 2;
+#define LMW_LAUNCH(PPT_, WPE_) hipLaunchKernelGGL((mds_lm_wave_kernel<PPT_, WPE_>), dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out)
+#define LMW_LAUNCH_W(PPT_) { if (wpe == 2) LMW_LAUNCH(PPT_, 2); else LMW_LAUNCH(PPT_, 1); }
         switch (ppt) {
-        case 1: hipLaunchKernelGGL(mds_lm_wave_kernel<1>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
-        case 2: hipLaunchKernelGGL(mds_lm_wave_kernel<2>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
-        case 3: hipLaunchKernelGGL(mds_lm_wave_kernel<3>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
-        default: hipLaunchKernelGGL(mds_lm_wave_kernel<4>, dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out); break;
+        case 1: LMW_LAUNCH_W(1) break;
+        case 2: LMW_LAUNCH_W(2) break;
+        case 3: LMW_LAUNCH_W(3) break;
+        default: LMW_LAUNCH_W(4) break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || p.nmax + 2 <= wave_rows) return e;
