@@ -76,6 +76,8 @@ struct Engine {
     double *T_wj0 = nullptr, *T_init = nullptr, *p_w = nullptr, *p_jt = nullptr;
     double *lm_work = nullptr, *lm_out = nullptr;
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
+    int32_t *lm_big = nullptr;           // MdsProblemDesc::big: the solves left to the workgroup form, two alternating lists
+    int lm_big_slot = 0;
     roam_lane_result *results = nullptr;           // ring of RES_RING per-step records (RES_RING x B)
     roam_lane_result *results_host = nullptr;      // pinned mirror, filled asynchronously after every step
     hipEvent_t ev_res[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -654,6 +656,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     ok = ok && dalloc(ctx, e, &e->lm_work, (size_t)B * ((size_t)(2 * KS + 3) * 9 + KS));
     ok = ok && dalloc(ctx, e, &e->lm_out, (size_t)B * 6);
     ok = ok && dalloc(ctx, e, &e->lm_nfev, (size_t)B);
+    ok = ok && dalloc(ctx, e, &e->lm_big, (size_t)2 * (1 + B));
     ok = ok && dalloc(ctx, e, &e->lm_info, (size_t)B);
     ok = ok && dalloc(ctx, e, &e->results, (size_t)B * RES_RING);
     if (ok && hipHostMalloc(reinterpret_cast<void **>(&e->results_host), sizeof(roam_lane_result) * (size_t)B * RES_RING, hipHostMallocDefault) != hipSuccess) {
@@ -1371,6 +1374,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         P.T_wj0 = e->T_wj0; P.T_init = e->T_init; P.p_w = e->p_w; P.p_jt = e->p_jt; P.count = e->in_n;
         P.N = KM; P.nstride = KS; P.nmax = KM; P.B = B; P.period = 0.25;
         for (int i = 0; i < 5; i++) P.sigma5[i] = c.sigma5[i];
+        P.big = e->lm_big; P.big_slot = e->lm_big_slot; e->lm_big_slot ^= 1;
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));

@@ -371,14 +371,12 @@ __device__ void lmpar6(int m, double *a, const int *ipvt, const double *diag, co
 // the pipelined engine it shares every SIMD with the warp / pyramid / tracker of other steps for its whole (latency-
 // bound) duration, and two 219-register wavefronts left room for nothing else (A/B: +1.9 % scan-pairs/s)
 #define LM_WPE 3
-__global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
-                                                      double *__restrict__ out6, int32_t *__restrict__ nfev_out,
-                                                      int32_t *__restrict__ info_out, double *__restrict__ x0_out,
-                                                      double *__restrict__ r0_out, int lds_bytes, int wave_rows)
+__device__ __forceinline__ void mds_lm_block_solve(const MdsProblemDesc &P, const int b, double *__restrict__ work_g,
+                                                   double *__restrict__ out6, int32_t *__restrict__ nfev_out,
+                                                   int32_t *__restrict__ info_out, double *__restrict__ x0_out,
+                                                   double *__restrict__ r0_out, int lds_bytes, int wave_rows, unsigned char *lm_smem, LmShared &S)
 {
-    extern __shared__ __align__(16) unsigned char lm_smem[];
-    __shared__ LmShared S;
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int N = P.count ? min(P.count[b], P.nmax) : P.N;
     const int m = 2 * N + 3, n = 6;
     if (N + 2 <= wave_rows) return;                   // mds_lm_wave_kernel's problem (launch_mds_solve)
@@ -653,6 +651,29 @@ __global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc 
     if (t == 0) { nfev_out[b] = S.nfev; info_out[b] = S.info; }
 }
 
+// one workgroup per problem - or, when the wave form has listed the problems it left (P.big), a few workgroups walking that list: with
+// a bound of 320 points and typical problems of 150, the 4 096 workgroups of a step that only had to return cost 0.46 ms on the
+// step's critical path (each waits for 32 KB of LDS beside the warp of the next step before it can do so)
+__global__ __launch_bounds__(LM_TMAX, LM_WPE) void mds_lm_kernel(MdsProblemDesc P, double *__restrict__ work_g,
+                                                      double *__restrict__ out6, int32_t *__restrict__ nfev_out,
+                                                      int32_t *__restrict__ info_out, double *__restrict__ x0_out,
+                                                      double *__restrict__ r0_out, int lds_bytes, int wave_rows)
+{
+    extern __shared__ __align__(16) unsigned char lm_smem[];
+    __shared__ LmShared S;
+    if (!P.big || wave_rows == 0) {
+        mds_lm_block_solve(P, blockIdx.x, work_g, out6, nfev_out, info_out, x0_out, r0_out, lds_bytes, wave_rows, lm_smem, S);
+        return;
+    }
+    const int32_t *L = P.big + (size_t)P.big_slot * (1 + P.B);
+    const int nbig = L[0];
+    for (int q = blockIdx.x; q < nbig; q += (int)gridDim.x) {
+        mds_lm_block_solve(P, L[1 + q], work_g, out6, nfev_out, info_out, x0_out, r0_out, lds_bytes, wave_rows, lm_smem, S);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.big[(size_t)(P.big_slot ^ 1) * (1 + P.B)] = 0;     // the next solve's list (its wave kernel runs after this one)
+}
+
 hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *work, double *out6,
                             int32_t *nfev, int32_t *info, double *x0_out, double *r0_out)
 {
@@ -690,7 +711,8 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     // the solve is a long chain of short reductions: with few points a single wavefront per problem
     // (workgroup barriers degenerate to no-ops, reductions stay in registers) has the lowest latency
     const int threads = p.nmax <= 192 ? 64 : (p.nmax <= 448 ? 128 : LM_TMAX);
-    hipLaunchKernelGGL(mds_lm_kernel, dim3(p.B), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds, wave_rows);
+    const int grid = (p.big && wave_rows) ? std::min(p.B, 64) : p.B;
+    hipLaunchKernelGGL(mds_lm_kernel, dim3(grid), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds, wave_rows);
     return hipGetLastError();
 }
 

@@ -146,6 +146,10 @@ struct MdsProblemDesc {
     int nmax;                // upper bound of count[] (sizes the LM working set); <= nstride
     double sigma5[5];
     double period;
+    // optional (engine): the problems too large for the one-wavefront form, listed by that kernel for the workgroup form:
+    // two slots of 1 + B ints (count, problem ids), zero on first use; big_slot alternates between consecutive solves of a stream
+    int32_t *big = nullptr;
+    int big_slot = 0;
 };
 // work: B x ((2*nmax+3) x 9 + nmax) doubles; out6: B x 6; nfev/info: B; x0/r0 optional
 hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *work, double *out6,

@@ -59,6 +59,41 @@ def test_engine_matches_oracle_pipeline(sequences, md, reject):
     ctx.close()
 
 
+def test_engine_lm_forms_mixed_in_one_batch():
+    """the motion-distortion solve has two kernel forms (one wavefront per problem up to 254 points, a workgroup above: kabsch_mds.hip);
+    in the engine the first lists the problems it leaves to the second - lanes of both kinds in one batch, over several steps (the two
+    lists alternate), against the oracle pipeline lane by lane"""
+    from radarslampy_amd import _ffi, synth
+    from radarslampy_amd.engine import Engine
+    recs, poses, feat = synth.make_sequence(11, 4, n_static=520, n_movers=0)
+    sizes = [len(feat), 120, min(len(feat), 330), 60, min(len(feat), 280), 200]
+    assert len(feat) >= 300
+    ctx = _ffi.Context(0)
+    B, T = len(sizes), 4
+    eng = Engine(B, T, ctx=ctx, reject_outliers=True, motion_distortion=True)
+    for t in range(T):
+        eng.upload_scan(t, recs[t])
+    pipes = []
+    for b, n in enumerate(sizes):
+        eng.init_lane(b, 0, feat[:n], poses[0])
+        pipes.append(oracle.OdometryPipeline(recs[0], feat[:n], poses[0], reject_outliers=True, motion_distortion=True))
+    seen = set()
+    for t in range(1, T):
+        eng.step([t] * B)
+        res = eng.results()
+        for b in range(B):
+            want, got = pipes[b].step(recs[t]), res[b]
+            tag = (t, b, sizes[b])
+            assert got["n_inliers"] == want["n_inliers"] and got["n_good"] == want["n_good"], tag
+            seen.add(got["n_inliers"] + 2 > 256)
+            assert np.abs(got["pose"][:2] - want["pose"][:2]).max() <= POS_TOL, (tag, got["pose"], want["pose"])
+            assert abs(got["pose"][2] - want["pose"][2]) <= ANG_TOL, (tag, got["pose"], want["pose"])
+            assert got["lm_info"] in (1, 2, 3, 4), (tag, got["lm_info"])
+    assert seen == {True, False}, "both kernel forms must have been exercised"
+    eng.close()
+    ctx.close()
+
+
 def test_engine_without_stage_events_gives_the_same_results():
     """roam_engine_set_stage_events(0) (what the single-sequence driver does): the step's timestamp events are not recorded - same
     results record for record, stage_times / kernel_avg refuse with a state error instead of reading stale events"""
