@@ -105,17 +105,55 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
     pinned = None if records_pinned else ctx.host_alloc((RING, rows, stride))
     it = iter(records)
     uploaded = 0
+    # Records that are not pinned go through a staging ring, and the 1.5 MB copy of a frame is a quarter of what this thread spends per
+    # frame (enqueue ~140 us, copy ~100 us: the single-sequence rate is the rate of THIS thread).  A feeder thread does the copies ahead
+    # (NumPy releases the GIL for them).  Ring slot f % RING is free for frame f once step f - RING has been collected: the copy stream
+    # is in order, so the upload of frame f - RING - the slot's only reader - is behind that step.
+    import threading
+    cv = threading.Condition()
+    st = dict(staged=0, collected=-1, done=False, stop=False, err=None)
+
+    def feeder():
+        f = 0
+        try:
+            for rec in it:
+                with cv:
+                    cv.wait_for(lambda: st["stop"] or f < RING or st["collected"] >= f - RING)
+                    if st["stop"]:
+                        return
+                pinned[f % RING] = rec
+                f += 1
+                with cv:
+                    st["staged"] = f
+                    cv.notify_all()
+        except BaseException as e:                                            # raised again by the consumer, at its turn
+            with cv:
+                st["err"] = e
+        finally:
+            with cv:
+                st["done"] = True
+                cv.notify_all()
+
+    th = None
+    if not records_pinned:
+        th = threading.Thread(target=feeder, name="roam-stage", daemon=True)
+        th.start()
 
     def upload_next():
         nonlocal uploaded
-        rec = next(it, None)
-        if rec is None:
-            return False
         slot = uploaded % RING
         if records_pinned:
+            rec = next(it, None)
+            if rec is None:
+                return False
             eng.upload_scans_async(slot, rec, n=1)
         else:
-            pinned[slot] = rec
+            with cv:
+                cv.wait_for(lambda: st["staged"] > uploaded or st["done"])
+                if st["staged"] <= uploaded:
+                    if st["err"] is not None:
+                        raise st["err"]
+                    return False
             eng.upload_scans_async(slot, pinned[slot], n=1)
         uploaded += 1
         return True
@@ -125,6 +163,10 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
 
     def collect(step):
         r = eng.results(step)[0]
+        if th is not None:
+            with cv:                                                          # step `step` consumed frame step + 1 (and every upload before it)
+                st["collected"] = step + 1
+                cv.notify_all()
         poses[step] = r["pose"]
         log.append(dict(n_tracked=r["n_tracked"], n_good=r["n_good"], n_inliers=r["n_inliers"], new_keyframe=r["new_keyframe"],
                         retrack=r["retrack"], n_after_retrack=r["n_after_retrack"], pose=r["pose"].copy(), velocity=r["velocity"].copy()))
@@ -156,9 +198,14 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
         if before_close is not None:
             before_close(eng)
     finally:
+        if th is not None:
+            with cv:
+                st["stop"] = True
+                cv.notify_all()
+            th.join()
+        eng.close()
         if pinned is not None:
             ctx.host_free(pinned)
-        eng.close()
         if own:
             ctx.close()
     return (poses, log, lat) if synchronous else (poses, log)

@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
                                                         roam_lane_result *__restrict__ res, const int32_t *__restrict__ scan_idx,
                                                         double *__restrict__ kf_vel, int32_t *__restrict__ kf_scan,
                                                         int32_t *__restrict__ kf_fresh, const int32_t *__restrict__ kf_live,
-                                                        double *__restrict__ map_store, int32_t *__restrict__ map_n, int map_cap)
+                                                        double *__restrict__ map_store, int32_t *__restrict__ map_n, int map_cap,
+                                                        int collect, int32_t *__restrict__ rt_lane, int32_t *__restrict__ rt_scan,
+                                                        int32_t *__restrict__ rt_n)
 {
     __shared__ double np_[3], nv_[3];
     __shared__ int newkf;
@@ -415,6 +417,38 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
         }
         kf_fresh[b] = newkf;
         feat_n[b] = n;
+    }
+    // The list of the lanes that re-detect (rt_collect_kernel's job: lane order, so one block) by the block that finishes LAST: one launch
+    // less in the chain every step enqueues (a kernel that only returns costs ~4-6 us of a single sequence's 290 us pair).
+    // collect: 0 none, 1 lanes with flag bit 2, 2 every lane; rt_n[1] counts the finished blocks and is left at zero
+    if (collect) {
+        __shared__ int last_s, sh[4], base_s;
+        __threadfence();
+        __syncthreads();
+        if (t == 0) last_s = atomicAdd(rt_n + 1, 1) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (!last_s) return;
+        __threadfence();
+        const int B = (int)gridDim.x;
+        if (t == 0) base_s = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < B; b0 += 256) {
+            const int bb = b0 + t;
+            const int f = (bb < B && (collect == 2 || (reinterpret_cast<volatile roam_lane_result *>(res)[bb].flags & 4))) ? 1 : 0;
+            const int lane = t & 63, w = t >> 6;
+            int inc = f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int nn = __shfl_up(inc, d); if (lane >= d) inc += nn; }
+            if (lane == 63) sh[w] = inc;
+            __syncthreads();
+            int off = base_s, tot = 0;
+            for (int i = 0; i < 4; i++) { if (i < w) off += sh[i]; tot += sh[i]; }
+            if (f) { rt_lane[off + inc - 1] = bb; rt_scan[off + inc - 1] = scan_idx[bb]; }
+            __syncthreads();
+            if (t == 0) base_s += tot;
+            __syncthreads();
+        }
+        if (t == 0) { rt_n[0] = base_s; rt_n[1] = 0; }
     }
 }
 
@@ -676,7 +710,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         const int R = r.slots = std::max(1, std::min(B, cfg->retrack_slots > 0 ? cfg->retrack_slots : 2048));      // (round 6: 512 -> 2048, +2.5 % on the default workload)
         const size_t npx = (size_t)e->W * e->W;
         if (e->W > 2048) { ROAM_SET_ERR(ctx, "engine: device retrack needs a Cartesian image of at most 2048 x 2048"); roam_engine_destroy(ctx); return ROAM_E_ARG; }
-        ok = ok && dalloc(ctx, e, &r.rt_n, 1) && dalloc(ctx, e, &r.rt_lane, (size_t)B) && dalloc(ctx, e, &r.rt_scan, (size_t)B);
+        ok = ok && dalloc(ctx, e, &r.rt_n, 2) && dalloc(ctx, e, &r.rt_lane, (size_t)B) && dalloc(ctx, e, &r.rt_scan, (size_t)B);
         // rows of the integral image start on 128-byte lines: a wave's 512-byte store then fills four whole lines (with the natural
         // pitch of 2024 doubles HBM saw 1.44 x the bytes written)
         r.SP = (e->W + 15) & ~15;
@@ -1382,13 +1416,13 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipLaunchKernelGGL(g4_update_kernel, dim3(B), dim3(256), 0, st, c, e->lm_out, e->lm_nfev, e->lm_info, e->kab_out, e->pose,
                        e->vel, e->kf_pose, e->kf_und, e->kf_und_tmp, e->p_jt, e->in_n, e->good_n, e->feat_n, e->peaks_n[pb],
                        e->cq_flags, res_slot, e->scan_idx[pb], e->kf_vel, e->kf_scan, e->kf_fresh, e->kf_live, e->map_store, e->map_n,
-                       e->map_cap);
+                       e->map_cap, (e->rt_on && e->rt_mode) ? (e->rt_mode == 2 ? 2 : 1) : 0, e->rt.rt_lane, e->rt.rt_scan, e->rt.rt_n);
     HIP_TRY(ctx, hipGetLastError());
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_RETRACK], st));
     if (e->rt_on && e->rt_mode) {
-        // lanes that ran out of features (flag bit 2): appendNewFeatures on the current scan + keyframe refresh, on the device
+        // lanes that ran out of features (flag bit 2; listed by g4_update_kernel's last block): appendNewFeatures on the current scan +
+        // keyframe refresh, on the device
         e->rt.res = res_slot;
-        HIP_TRY(ctx, launch_retrack_collect(st, res_slot, e->scan_idx[pb], B, e->rt_mode == 2, e->rt));
         if (e->pyr_after_int && !e->ev_int) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_int, hipEventDisableTiming));
         HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1));
         if (e->pyr_after_int) e->ev_int_valid = true;

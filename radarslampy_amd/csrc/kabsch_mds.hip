@@ -711,7 +711,8 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     // the solve is a long chain of short reductions: with few points a single wavefront per problem
     // (workgroup barriers degenerate to no-ops, reductions stay in registers) has the lowest latency
     const int threads = p.nmax <= 192 ? 64 : (p.nmax <= 448 ? 128 : LM_TMAX);
-    const int grid = (p.big && wave_rows) ? std::min(p.B, 64) : p.B;
+    static const int big_grid = getenv("ROAM_LM_BIG_GRID") ? atoi(getenv("ROAM_LM_BIG_GRID")) : 512;
+    const int grid = (p.big && wave_rows) ? std::min(p.B, big_grid) : p.B;
     hipLaunchKernelGGL(mds_lm_kernel, dim3(grid), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds, wave_rows);
     return hipGetLastError();
 }

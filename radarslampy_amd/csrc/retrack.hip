@@ -1410,22 +1410,23 @@ extern "C" int roam_debug_blob_prof(unsigned long long *out, int reset)
 #else
 #define RB_P(k)
 #endif
+// the bookkeeping of one detection (one wavefront); -> 1 when the small class left it to the full one (kp_n = RT_BLOBS_REDO)
 template <bool SMALL>
-__global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
+__device__ int rt_blobs_body(const RtArgs &a, int first, RtBlobLds<SMALL> &L, bool forced)
 {
 #ifdef RB_EXP_PROF
     unsigned long long rbp_[12] = {0}, rbt_ = __builtin_readcyclecounter();
 #endif
     typedef RtBlobCap<SMALL> CP;
-    __shared__ RtBlobLds<SMALL> L;
+    // (L: the workgroup's LDS, the caller's)
     const int ls = a.blob_order ? a.blob_order[blockIdx.x] : (int)blockIdx.x, slot = first + ls;
-    if (slot >= *a.rt_n) return;
+    if (slot >= *a.rt_n) return 0;
     const int lane = threadIdx.x;
     const int ncand = a.cand_n[ls];
-    if (!SMALL && a.kp_n[ls] != RT_BLOBS_REDO) return;                      // the small kernel did it
+    if (!SMALL && !forced && a.kp_n[ls] != RT_BLOBS_REDO) return 0;                      // the small kernel did it
     if (SMALL && ncand > CP::NP) {
         if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
-        return;
+        return 1;
     }
     const int n = min(ncand, BP_MAX_PTS);
     const uint32_t *crc = a.cand_rc + (int64_t)ls * BP_MAX_PTS;
@@ -1527,7 +1528,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     __syncthreads();
     if (SMALL && nn < 0) {                                                   // more tree nodes than the small class holds: the full kernel's
         if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
-        return;
+        return 1;
     }
     for (int i = lane; i < n; i += 64) L.idx[i] = (int16_t)(pt[i].v >> 32);          // cKDTree.indices
     __syncthreads();
@@ -1662,7 +1663,7 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     // 4. which pairs overlap by more than 0.5 (original sigmas: a pair with a pruned member never changes anything)
     if (SMALL && np > CP::LDS_PAIRS) {                                       // more pairs than the small set tables order: the full kernel's
         if (lane == 0) a.kp_n[ls] = RT_BLOBS_REDO;
-        return;
+        return 1;
     }
     const bool lds_set = np <= CP::LDS_PAIRS, lds_pl = np <= CP::NPL;
     uint32_t *ovb = lds_set ? L.ovbits : a.ovbits + (int64_t)ls * ((BP_MAX_PAIRS + 31) / 32 + 1);
@@ -1764,6 +1765,25 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&rb_prof[k], rbp_[k]);
     if (lane == 0) { atomicAdd(&rb_prof[12], 1ull); atomicAdd(&rb_prof[13], (unsigned long long)n); atomicAdd(&rb_prof[14], (unsigned long long)mb); }
 #endif
+    return 0;
+}
+
+// large batches: every detection through the small class (33 KB of LDS: four per CU), then the few it left through the full one (64 KB)
+template <bool SMALL>
+__global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
+{
+    __shared__ RtBlobLds<SMALL> L;
+    rt_blobs_body<SMALL>(a, first, L, false);
+}
+// small batches (a single sequence's lone detection): both classes in ONE launch - the full one's LDS per workgroup, one kernel less in the
+// chain every step enqueues whether or not a lane re-detects
+__global__ __launch_bounds__(64) void rt_blobs_both_kernel(RtArgs a, int first)
+{
+    __shared__ union U_ { RtBlobLds<true> s; RtBlobLds<false> f; __device__ U_() {} } L;
+    if (rt_blobs_body<true>(a, first, L.s, false)) {
+        __syncthreads();
+        rt_blobs_body<false>(a, first, L.f, true);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K7: append + keyframe refresh
@@ -1986,8 +2006,11 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if ((e = launch_order_by_count(st, a.cand_n, B, BP_MAX_PTS, a.blob_order_buf, 1)) != hipSuccess) return e;
         ab.blob_order = a.blob_order_buf;
     }
-    hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, ab, 0);
-    hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, ab, 0);
+    if (B >= 256) {
+        hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, ab, 0);
+        hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, ab, 0);
+    } else
+        hipLaunchKernelGGL(rt_blobs_both_kernel, dim3(B), dim3(64), 0, st, ab, 0);
     e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rt_append_kernel, dim3(B), dim3(256), 0, st, a, 0);
