@@ -23,8 +23,8 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/one/prof/*/*kernel_trace.csv")[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]) for r in csv.DictReader(open(f))))
-# the last detection: from the last rt_collect_kernel on
-i0 = max(i for i, r in enumerate(rows) if r[2].startswith("rt_collect"))
+# the last detection: from the last g4_update_kernel on (its last block lists the lanes that re-detect)
+i0 = max(i for i, r in enumerate(rows) if r[2].startswith("g4_update"))
 t0 = rows[i0][0]
 for s, e, n in rows[i0:]:
     if e - s > 3000 or n.startswith("rt_") or n.startswith("ssc"):

@@ -18,6 +18,7 @@
 // batch dimension is what fills the 256 CUs; within a lane the chain is sequential.
 #include "roam_internal.h"
 #include "retrack.h"
+#include "kabsch_body.inc"
 #include <algorithm>
 #include <new>
 
@@ -242,9 +243,12 @@ __global__ __launch_bounds__(256) void g2_inliers_kernel(const float *__restrict
                                                          const double *__restrict__ kf_und, double *__restrict__ kf_und_tmp,
                                                          double *__restrict__ kab_src, double *__restrict__ kab_tgt,
                                                          double *__restrict__ p_w, double *__restrict__ p_jt,
-                                                         float *__restrict__ feat, int32_t *__restrict__ in_n)
+                                                         float *__restrict__ feat, int32_t *__restrict__ in_n,
+                                                         double *__restrict__ kab_out, const double *__restrict__ pose,
+                                                         double *__restrict__ T_wj0, double *__restrict__ T_init)
 {
     __shared__ int sh[8];
+    __shared__ double red[8];
     const int b = blockIdx.x, t = threadIdx.x;
     const int G = good_n[b];
     const int items = (KS + 255) / 256;
@@ -283,24 +287,26 @@ __global__ __launch_bounds__(256) void g2_inliers_kernel(const float *__restrict
         pos++;
     }
     if (t == 0) in_n[b] = total;
+    // The Kabsch fit of the lane's inliers (getTransformKLT.calculateTransformSVD) and, with motion distortion, the LM's two transforms
+    // (G3) by the same workgroup: kernels of their own until round 6 - two launches less in the chain of a step (a single sequence's pair is
+    // a chain of ~20 launches of 4-6 us each on the device and on the enqueuing thread)
+    __threadfence_block();
+    __syncthreads();
+    double *ko = kab_out + 6 * (int64_t)b;
+    kabsch_body(kab_src + (int64_t)b * KS * 2, kab_tgt + (int64_t)b * KS * 2, total, red, ko);
+    if (T_wj0 && t == 0) {
+        const double x = pose[3 * b], y = pose[3 * b + 1], th = pose[3 * b + 2];
+        const double c = cos(th), s = sin(th);
+        double *T0 = T_wj0 + 9 * (int64_t)b, *Ti = T_init + 9 * (int64_t)b;
+        T0[0] = c; T0[1] = -s; T0[2] = x; T0[3] = s; T0[4] = c; T0[5] = y; T0[6] = 0; T0[7] = 0; T0[8] = 1;
+        const double hx = ko[4] * M_PER_PX, hy = ko[5] * M_PER_PX;
+        Ti[0] = c * ko[0] - s * ko[2]; Ti[1] = c * ko[1] - s * ko[3]; Ti[2] = c * hx - s * hy + x;
+        Ti[3] = s * ko[0] + c * ko[2]; Ti[4] = s * ko[1] + c * ko[3]; Ti[5] = s * hx + c * hy + y;
+        Ti[6] = 0; Ti[7] = 0; Ti[8] = 1;
+    }
 }
 
-// G3: h *= 0.0864 (Tracker.py:124-125); T_wj = prev_pose @ [[R,h],[0,0,1]] (RawROAMSystem.py:201)
-__global__ void g3_init_transform_kernel(const double *__restrict__ kab_out, const double *__restrict__ pose,
-                                         double *__restrict__ T_wj0, double *__restrict__ T_init, int B)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double *k = kab_out + 6 * (int64_t)b;
-    const double x = pose[3 * b], y = pose[3 * b + 1], th = pose[3 * b + 2];
-    const double c = cos(th), s = sin(th);
-    double *T0 = T_wj0 + 9 * (int64_t)b, *Ti = T_init + 9 * (int64_t)b;
-    T0[0] = c; T0[1] = -s; T0[2] = x; T0[3] = s; T0[4] = c; T0[5] = y; T0[6] = 0; T0[7] = 0; T0[8] = 1;
-    const double hx = k[4] * M_PER_PX, hy = k[5] * M_PER_PX;
-    Ti[0] = c * k[0] - s * k[2]; Ti[1] = c * k[1] - s * k[3]; Ti[2] = c * hx - s * hy + x;
-    Ti[3] = s * k[0] + c * k[2]; Ti[4] = s * k[1] + c * k[3]; Ti[5] = s * hx + c * hy + y;
-    Ti[6] = 0; Ti[7] = 0; Ti[8] = 1;
-}
+// (G3 - h *= 0.0864 (Tracker.py:124-125); T_wj = prev_pose @ [[R,h],[0,0,1]] (RawROAMSystem.py:201) - is the tail of g2_inliers_kernel)
 
 // f1 keyframe map: one slot = 8-double header {pose[3], velocity[3], n, scan} + KS x 2 undistorted locals
 #define MAP_SLOT (8 + 2 * KS)
@@ -385,7 +391,8 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
         r->n_tracked = feat_n[b]; r->n_good = good_n[b]; r->n_inliers = n; r->n_peaks = peaks_n[b];
         r->lm_nfev = (n >= 2 && cfg.motion_distortion) ? lm_nfev[b] : 0;
         r->lm_info = (n >= 2 && cfg.motion_distortion) ? lm_info[b] : 0;
-        r->flags = (cq_flags[b] & 1) | (newkf ? 2 : 0) | (retrack ? 4 : 0);
+        // (a device-scope atomic store: the last block of this kernel reads every lane's flags, possibly from another XCD - see below)
+        __hip_atomic_store(&r->flags, (cq_flags[b] & 1) | (newkf ? 2 : 0) | (retrack ? 4 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         r->n_after_retrack = 0;
     }
     __syncthreads();
@@ -423,18 +430,18 @@ __global__ __launch_bounds__(256) void g4_update_kernel(roam_engine_cfg cfg, con
     // collect: 0 none, 1 lanes with flag bit 2, 2 every lane; rt_n[1] counts the finished blocks and is left at zero
     if (collect) {
         __shared__ int last_s, sh[4], base_s;
-        __threadfence();
+        // (no __threadfence(): on this GPU it writes the XCD's whole L2 back; the flags travel as device-scope atomics, the counter after them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) last_s = atomicAdd(rt_n + 1, 1) == (int)gridDim.x - 1;
         __syncthreads();
         if (!last_s) return;
-        __threadfence();
         const int B = (int)gridDim.x;
         if (t == 0) base_s = 0;
         __syncthreads();
         for (int b0 = 0; b0 < B; b0 += 256) {
             const int bb = b0 + t;
-            const int f = (bb < B && (collect == 2 || (reinterpret_cast<volatile roam_lane_result *>(res)[bb].flags & 4))) ? 1 : 0;
+            const int f = (bb < B && (collect == 2 || (__hip_atomic_load(&res[bb].flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4))) ? 1 : 0;
             const int lane = t & 63, w = t >> 6;
             int inc = f;
 #pragma unroll
@@ -719,6 +726,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.darktab), retrack_darktab_words(e->W));
         ok = ok && dalloc(ctx, e, const_cast<uint32_t **>(&r.phlist), retrack_phase_words(e->W));
         ok = ok && dalloc(ctx, e, &r.colT, (size_t)std::min(R, RT_TWO_PASS_SLOTS) * ((e->W + 63) / 64) * e->W);
+        ok = ok && dalloc(ctx, e, &r.col_done, (size_t)std::min(R, RT_TWO_PASS_SLOTS) * 64);
         // the fused detection kernel (retrack_fused.inc: integral image + determinants + maxima without the float64 image in HBM) serves
         // chunks of >= RT_TWO_PASS_SLOTS detections when ROAM_FUSED_DETECT=1 asks for it.  It is bit-identical to the two-kernel form
         // (tests/test_gpu_fused_detect.py) and MEASURED SLOWER - 27 ms against 12.6 ms per 512 detections, DESIGN.md section 6e: the path is
@@ -1395,13 +1403,9 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     }
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_KABSCH], st));
     hipLaunchKernelGGL(g2_inliers_kernel, dim3(B), dim3(256), 0, st, e->good_old, e->good_new, e->good_idx, e->good_n, e->cq_mask,
-                       e->kf_pose, e->kf_und, e->kf_und_tmp, e->kab_src, e->kab_tgt, e->p_w, e->p_jt, e->feat, e->in_n);
+                       e->kf_pose, e->kf_und, e->kf_und_tmp, e->kab_src, e->kab_tgt, e->p_w, e->p_jt, e->feat, e->in_n, e->kab_out, e->pose,
+                       c.motion_distortion ? e->T_wj0 : nullptr, e->T_init);                 // (T_wj0 / T_init feed the LM solve only)
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, launch_kabsch(st, e->kab_src, e->kab_tgt, e->in_n, KM, KS, B, e->kab_out));
-    if (c.motion_distortion) {                                           // (T_wj0 / T_init feed the LM solve only)
-        hipLaunchKernelGGL(g3_init_transform_kernel, dim3((B + 63) / 64), dim3(64), 0, st, e->kab_out, e->pose, e->T_wj0, e->T_init, B);
-        HIP_TRY(ctx, hipGetLastError());
-    }
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_LM], st));
     if (c.motion_distortion) {
         MdsProblemDesc P;

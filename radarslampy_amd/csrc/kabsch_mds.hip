@@ -19,77 +19,15 @@
 #define LM_TMAX 256
 #define TWO_PI 6.283185307179586476925286766559
 
-// wavefront sum returned to every lane.  The solve is a chain of short dependent reductions, so the
-// latency of one reduction matters: four DPP steps (quad xor 1, quad xor 2, half-row mirror, row
-// mirror: ~10 cycles each, against ~100 for a ds_bpermute shuffle) leave the 16-lane row sums in
-// every lane of the row, the four row sums are then read as scalars and added in a fixed order.
-template <int CTRL> __device__ __forceinline__ double dpp_move_d(double v)
-{
-    const long long bits = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+#include "kabsch_body.inc"
 
-__device__ __forceinline__ double readlane_d(double v, int l)
-{
-    const long long bits = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), l);
-    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), l);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-    v += dpp_move_d<0xB1>(v);        // quad_perm [1,0,3,2]
-    v += dpp_move_d<0x4E>(v);        // quad_perm [2,3,0,1]
-    v += dpp_move_d<0x141>(v);       // row_half_mirror
-    v += dpp_move_d<0x140>(v);       // row_mirror
-    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
-}
-
-// block-wide sum, result returned to every thread (deterministic order)
-__device__ __forceinline__ double block_sum_d(double v, double *red)
-{
-    v = wave_sum_d(v);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[w] = v;
-    __syncthreads();
-    double s = 0;
-    const int nw = blockDim.x >> 6;
-    for (int i = 0; i < nw; i++) s += red[i];
-    return s;
-}
-
-// ------------------------------------------------------------------------------ Kabsch
 __global__ __launch_bounds__(256) void kabsch_kernel(const double *__restrict__ src, const double *__restrict__ tgt,
                                                      const int32_t *__restrict__ count, int N, int nstride,
                                                      double *__restrict__ out6)
 {
     __shared__ double red[8];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int n = count ? count[b] : N;
-    const double *s = src + (int64_t)b * nstride * 2, *g = tgt + (int64_t)b * nstride * 2;
-    double sx = 0, sy = 0, tx = 0, ty = 0;
-    for (int i = t; i < n; i += 256) { sx += s[2 * i]; sy += s[2 * i + 1]; tx += g[2 * i]; ty += g[2 * i + 1]; }
-    sx = block_sum_d(sx, red); sy = block_sum_d(sy, red); tx = block_sum_d(tx, red); ty = block_sum_d(ty, red);
-    const double inv = n > 0 ? 1.0 / (double)n : 0.0;
-    const double msx = sx * inv, msy = sy * inv, mtx = tx * inv, mty = ty * inv;
-    double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-    for (int i = t; i < n; i += 256) {
-        double ax = s[2 * i] - msx, ay = s[2 * i + 1] - msy, bx = g[2 * i] - mtx, by = g[2 * i + 1] - mty;
-        c00 += ax * bx; c01 += ax * by; c10 += ay * bx; c11 += ay * by;
-    }
-    c00 = block_sum_d(c00, red); c01 = block_sum_d(c01, red); c10 = block_sum_d(c10, red); c11 = block_sum_d(c11, red);
-    if (t == 0) {
-        const double th = atan2(c10 - c01, c00 + c11);
-        const double c = cos(th), sn = sin(th);
-        double *o = out6 + (int64_t)b * 6;
-        o[0] = c; o[1] = -sn; o[2] = sn; o[3] = c;
-        o[4] = msx - (c * mtx - sn * mty);
-        o[5] = msy - (sn * mtx + c * mty);
-    }
+    const int b = blockIdx.x;
+    kabsch_body(src + (int64_t)b * nstride * 2, tgt + (int64_t)b * nstride * 2, count ? count[b] : N, red, out6 + (int64_t)b * 6);
 }
 
 hipError_t launch_kabsch(hipStream_t st, const double *src, const double *tgt, const int32_t *count,

@@ -28,6 +28,7 @@ struct RtArgs {
     int32_t *rt_n, *rt_lane, *rt_scan;
     // per-slot scratch (slots entries): the image-scale kernels work on chunks of `slots` detections
     double *S;                      // W rows x SP float64: integral image, rows padded to whole 128-byte lines
+    int32_t *col_done;              // two-pass integral image: finished bands per (slot, column group of 64): RT_TWO_PASS_SLOTS x 64, zero between launches
     double *colT;                   // two-pass integral image (small chunks): ceil(W / 64) band totals x W columns, RT_TWO_PASS_SLOTS slots
     int SP;                         // row pitch of S in elements (a multiple of 16, >= W)
     // per-detection scratch (one entry per lane: the bookkeeping kernels run once over all detections of a step)

@@ -70,7 +70,7 @@ __device__ __forceinline__ float rt_code_to_f32(uint32_t k) { return (float)__dm
 // Two ways to the integral image, chosen on the device by the number of detections of the chunk (only the device knows it):
 //   * rt_integral_kernel (below): one workgroup per detection, the image written once - 12.7 us per detection at 512, but a chain of
 //     1016 dependent phases per detection: 6.5 ms per chunk whatever its size
-//   * rt_integ_cols_kernel + rt_integ_colfix_kernel + rt_integ_rows_kernel: thousands of threads per detection, three times the
+//   * rt_integ_cols_kernel (+ the band fix-up by its last workgroups) + rt_integ_rows_kernel: thousands of threads per detection, three times the
 //     traffic, 0.26 ms for one alone
 // Both are launched; the one whose regime it is not returns at once.
 #define RI_MIN_DETECTIONS RT_TWO_PASS_SLOTS
@@ -107,8 +107,8 @@ __device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict_
 // sum is EXACT in float64, in any order.  So the 64 rows of a band's column are four threads of 16 rows each (round 6; one thread per
 // band column until then: 16 dependent pairs of round trips - map word, then taps - were 48 of a lone detection's 54 us in this pass):
 // all 16 map words leave at once, then all 64 taps, the quarters' totals meet in LDS; the workgroup writes the band-local sums and the
-// band's total; rt_integ_colfix_kernel turns the totals into what lies above each band, and the row pass adds that in as it loads (all
-// exact = NumPy's values).
+// band's total; the last workgroup of a column group turns the totals into what lies above each band, and the row pass adds that in as
+// it loads (all exact = NumPy's values).
 #define RC_BAND 64
 #define RC_Q 16                              // rows per thread: RC_BAND / 4
 __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
@@ -138,31 +138,36 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
     __syncthreads();
     double base = 0;
     for (int j = 0; j < q; j++) base = __dadd_rn(base, tot[j][lane]);
-    if (c >= W) return;
+    if (c < W) {
 #pragma unroll
-    for (int k = 0; k < RC_Q; k++)
-        if (r0 + k < W) S[(int64_t)(r0 + k) * a.SP + c] = __dadd_rn(base, s[k]);
-    if (q == 3) a.colT[((int64_t)ls * nb + band) * W + c] = __dadd_rn(base, acc);
-}
-
-// band totals -> sum of the bands above (exclusive prefix per column; exact, see above); the totals are loaded 32 at a time (one round
-// trip instead of one per band: the store of band b kept the compiler from moving the load of band b + 1 above it - 11 us alone)
-__global__ __launch_bounds__(256) void rt_integ_colfix_kernel(RtArgs a, int first)
-{
-    const int ls = blockIdx.y, slot = first + ls;
-    if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
-    const int c = blockIdx.x * 256 + threadIdx.x, W = a.W, nb = (W + RC_BAND - 1) / RC_BAND;
-    if (c >= W) return;
-    double *T = a.colT + (int64_t)ls * nb * W + c;
-    double run = 0.0;
-    for (int b0 = 0; b0 < nb; b0 += 32) {
-        double tv[32];
-#pragma unroll
-        for (int j = 0; j < 32; j++) tv[j] = b0 + j < nb ? T[(int64_t)(b0 + j) * W] : 0.0;
-#pragma unroll
-        for (int j = 0; j < 32; j++)
-            if (b0 + j < nb) { T[(int64_t)(b0 + j) * W] = run; run = __dadd_rn(run, tv[j]); }
+        for (int k = 0; k < RC_Q; k++)
+            if (r0 + k < W) S[(int64_t)(r0 + k) * a.SP + c] = __dadd_rn(base, s[k]);
+        if (q == 3) __hip_atomic_store(a.colT + ((int64_t)ls * nb + band) * W + c, __dadd_rn(base, acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // band totals -> sum of the bands above (exclusive prefix per column; exact, see above), by the workgroup of this column group that
+    // finishes LAST (a kernel of its own until round 6: one launch more in the chain every step enqueues); the totals are loaded 32 at a
+    // time (one round trip instead of one per band).  col_done[detection][column group] counts the finished bands and is left at zero.
+    // The totals cross between workgroups - between XCDs, each with an L2 of its own - as device-scope atomic stores and loads, the
+    // counter after them: a __threadfence() here writes the XCD's whole L2 back, 32 MB of integral image included (151 us instead of 18).
+    __shared__ int last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = atomicAdd(a.col_done + ls * 64 + (int)blockIdx.x, 1) == nb - 1;
+    __syncthreads();
+    if (!last_s) return;
+    if (q == 0 && c < W) {
+        double *T = a.colT + (int64_t)ls * nb * W + c;
+        double run = 0.0;
+        for (int b0 = 0; b0 < nb; b0 += 32) {
+            double tv[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) tv[j] = b0 + j < nb ? __hip_atomic_load(T + (int64_t)(b0 + j) * W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; j++)
+                if (b0 + j < nb) { T[(int64_t)(b0 + j) * W] = run; run = __dadd_rn(run, tv[j]); }
+        }
+    }
+    if (threadIdx.x == 0) a.col_done[ls * 64 + (int)blockIdx.x] = 0;
 }
 
 // Row pass: a workgroup per 16 rows; 16 lanes of wave 0, lane = row, walk sequentially along the row (the reference's summation order);
@@ -1021,6 +1026,7 @@ __global__ __launch_bounds__(SD_THREADS) void rt_det_strip_kernel(RtArgs a, int 
 }
 
 #include "retrack_fused.inc"
+#include "ssc_body.inc"
 
 // ------------------------------------------------------------------------------------------------ K4: ordered candidates
 // the candidates of a detection (at most BP_MAX_PTS are kept) sorted by (row, column, layer): keys are unique, so a key's rank is
@@ -1775,15 +1781,54 @@ __global__ __launch_bounds__(64) void rt_blobs_kernel(RtArgs a, int first)
     __shared__ RtBlobLds<SMALL> L;
     rt_blobs_body<SMALL>(a, first, L, false);
 }
-// small batches (a single sequence's lone detection): both classes in ONE launch - the full one's LDS per workgroup, one kernel less in the
-// chain every step enqueues whether or not a lane re-detects
-__global__ __launch_bounds__(64) void rt_blobs_both_kernel(RtArgs a, int first)
+// small batches (a single sequence's lone detection): K4 (candidate order), K5 (both classes) and K6 (SSC) of a detection in ONE launch,
+// one wavefront - three kernels less in the chain every step enqueues whether or not a lane re-detects (a kernel that only returns costs
+// 4-6 us of the device and of the enqueuing thread; a single sequence's pair is 290 us).  The full class's LDS per workgroup; the same
+// code, so the same results; K4 on 64 threads instead of 256 costs a lone detection ~10 us.
+__global__ __launch_bounds__(64) void rt_book_kernel(RtArgs a, int first)
 {
-    __shared__ union U_ { RtBlobLds<true> s; RtBlobLds<false> f; __device__ U_() {} } L;
+    __shared__ union U_ {
+        RtBlobLds<true> s; RtBlobLds<false> f;
+        struct { uint32_t key[BP_MAX_PTS]; double val[BP_MAX_PTS]; } e;
+        uint32_t bitmap[SSC_BATCH_BITMAP_BYTES / 4];
+        __device__ U_() {}
+    } L;
+    const int ls = blockIdx.x, slot = first + ls, lane = threadIdx.x;
+    if (slot >= *a.rt_n) return;
+    {   // K4 (rt_emit_kernel)
+        const int n = min(a.cand_n[ls], BP_MAX_PTS);
+        uint32_t *crc = a.cand_rc + (int64_t)ls * BP_MAX_PTS;
+        double *cval = a.cand_val + (int64_t)ls * BP_MAX_PTS;
+        for (int i = lane; i < n; i += 64) { L.e.key[i] = crc[i]; L.e.val[i] = cval[i]; }
+        __syncthreads();
+        for (int i0 = lane; i0 < n; i0 += 256) {
+            uint32_t k[4];
+            int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) k[u] = i0 + 64 * u < n ? L.e.key[i0 + 64 * u] : 0u;
+            for (int j = 0; j < n; j++) {
+                const uint32_t kj = L.e.key[j];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rank[u] += kj < k[u] ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 64 * u < n) { crc[rank[u]] = k[u]; cval[rank[u]] = L.e.val[i0 + 64 * u]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");                   // the lists are read back (by other lanes) right below
+        __syncthreads();
+    }
     if (rt_blobs_body<true>(a, first, L.s, false)) {
         __syncthreads();
         rt_blobs_body<false>(a, first, L.f, true);
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __syncthreads();
+    // K6 (ssc_batch_kernel)
+    const int nk = min(a.kp_n[ls], BP_MAX_PTS);
+    if (nk <= 0) { if (lane == 0) a.sel_n[ls] = 0; return; }
+    ssc_body(a.kp + (int64_t)ls * BP_MAX_PTS * 3, nk, 200, 0.1, a.W, a.W, a.ssc_work + (int64_t)ls * 4 * BP_MAX_PTS,
+             a.sel + (int64_t)ls * BP_MAX_PTS, a.sel_n + ls, L.bitmap, SSC_BATCH_BITMAP_BYTES);
 }
 
 // ------------------------------------------------------------------------------------------------ K7: append + keyframe refresh
@@ -1988,7 +2033,6 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
-        hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, first);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, first);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
@@ -1997,22 +2041,26 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if (after_integral && after_det == 1 && first + R >= B && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[2], st)) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
-    // the bookkeeping is one latency-bound wavefront per detection and its time grows with the candidate list: longest lists first
-    // (in the default step 2.1 -> ... ms for the kernel; the work is the same, the tail is not)
-    RtArgs ab = a;
-    ab.blob_order = nullptr;
-    if (B >= 512 && a.blob_order_buf) {
-        if ((e = launch_order_by_count(st, a.cand_n, B, BP_MAX_PTS, a.blob_order_buf, 1)) != hipSuccess) return e;
-        ab.blob_order = a.blob_order_buf;
-    }
-    if (B >= 256) {
+    if (B < 256) {
+        RtArgs ab = a;
+        ab.blob_order = nullptr;
+        hipLaunchKernelGGL(rt_book_kernel, dim3(B), dim3(64), 0, st, ab, 0);                 // K4 + K5 + K6 in one launch
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
+        // the bookkeeping is one latency-bound wavefront per detection and its time grows with the candidate list: longest lists first
+        // (in the default step 2.1 -> ... ms for the kernel; the work is the same, the tail is not)
+        RtArgs ab = a;
+        ab.blob_order = nullptr;
+        if (B >= 512 && a.blob_order_buf) {
+            if ((e = launch_order_by_count(st, a.cand_n, B, BP_MAX_PTS, a.blob_order_buf, 1)) != hipSuccess) return e;
+            ab.blob_order = a.blob_order_buf;
+        }
         hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, ab, 0);
         hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, ab, 0);
-    } else
-        hipLaunchKernelGGL(rt_blobs_both_kernel, dim3(B), dim3(64), 0, st, ab, 0);
-    e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
-    if (e != hipSuccess) return e;
+        e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(rt_append_kernel, dim3(B), dim3(256), 0, st, a, 0);
     if (after_integral && after_det == 2 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;     // (after the whole chain)
     return hipGetLastError();
@@ -2046,7 +2094,6 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a_in, int P, int wh
         hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, 0);
-        hipLaunchKernelGGL(rt_integ_colfix_kernel, dim3((W + 255) / 256, P2), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, 0);
     } else {
         return launch_det(st, a, 0, P);                                     // (the caller clears the candidate counts: no bookkeeping follows that would)
