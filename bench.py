@@ -292,6 +292,22 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             stream_recs = stream_render(args, True)                # the --stream segment's records, before the GPU is touched
         from radarslampy_amd import _ffi
         from radarslampy_amd.engine import Engine
+        stream_cfg = {}
+        if stream_recs is not None:
+            # BASELINE configs 3 / 4 on the same clock: ONE sequence through a 1-lane engine (records rendered before the timed region).
+            # Measured BEFORE the 4 096-lane engine exists, i.e. as `python bench.py --stream` measures it: a process that has created
+            # and closed such an engine (67 GB of detection scratch) enqueues ~8 % slower afterwards (profiles/pageable_effect.py), and
+            # a single sequence's rate is its enqueue rate
+            sctx = _ffi.Context(local_rank)
+            for md_ in (True, False):
+                _, cfg_ = stream_measure(stream_recs[0], stream_recs[1], md_, sctx)
+                tag = "md_on" if md_ else "md_off"
+                stream_cfg[f"stream_pairs_per_s_{tag}"] = cfg_["pipelined_pairs_per_s"]
+                stream_cfg[f"stream_ms_per_pair_awaited_{tag}"] = cfg_["latency_ms_per_pair"]["median"]
+                stream_cfg[f"stream_ms_retrack_pair_awaited_{tag}"] = cfg_["latency_ms_per_pair"]["median_retrack_pair"]
+            stream_cfg["stream_segment"] = (f"{len(stream_recs[0])} frames along full_seq_1's ground-truth motions, 1 lane, pinned ring + result ring, "
+                                            "measured before the batch engine is created; = python bench.py --stream [--no-md]")
+            sctx.close()
         ctx = _ffi.Context(local_rank)
         info = ctx.device_info()
         comm = None
@@ -614,17 +630,7 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
     for c in ctxs:
         c.close()
     if out is not None and stream_recs is not None:
-        # BASELINE configs 3 / 4 on the same clock: ONE sequence through a 1-lane engine (records rendered before the timed region)
-        from radarslampy_amd import _ffi
-        sctx = _ffi.Context(local_rank)
-        for md_ in (True, False):
-            _, cfg_ = stream_measure(stream_recs[0], stream_recs[1], md_, sctx)
-            tag = "md_on" if md_ else "md_off"
-            out["config"][f"stream_pairs_per_s_{tag}"] = cfg_["pipelined_pairs_per_s"]
-            out["config"][f"stream_ms_per_pair_awaited_{tag}"] = cfg_["latency_ms_per_pair"]["median"]
-            out["config"][f"stream_ms_retrack_pair_awaited_{tag}"] = cfg_["latency_ms_per_pair"]["median_retrack_pair"]
-        out["config"]["stream_segment"] = f"{len(stream_recs[0])} frames along full_seq_1's ground-truth motions, 1 lane, pinned ring + result ring; = python bench.py --stream [--no-md]"
-        sctx.close()
+        out["config"].update(stream_cfg)
     if out is not None:
         print(json.dumps(out), flush=True)
 
