@@ -121,6 +121,8 @@ struct Engine {
     hipEvent_t rt_ev[64][3 * RT_TRACE_CHUNKS] = {};                    // every detection chunk of a step (the first RT_TRACE_CHUNKS): before | integral image | determinants
     bool rt_ev_ok[64] = {};
     hipEvent_t ev_int = nullptr;                    // after the integral images of a step's (first) detection chunk
+    hipEvent_t ev_emit = nullptr;                   // after the first bookkeeping kernels behind the determinants (ROAM_PYR_AFTER_EMIT / ROAM_PEAKS_AFTER_EMIT)
+    int pyr_after_emit = 0, peaks_after_emit = 0;
     bool ev_int_valid = false;
     int warp_after_int = 0;                         // ROAM_WARP_AFTER_INTEGRAL (experiment)
     int peaks_after_int = 0;                        // ROAM_PEAKS_AFTER_INTEGRAL (experiment): the peak kernel waits for the same event as the pyramid
@@ -588,6 +590,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     // every event handle starts out null, so a creation that failed half way leaks nothing
     auto kill = [](hipEvent_t &ev) { if (ev) { hipEventDestroy(ev); ev = nullptr; } };
     for (auto &ev : e->ev) kill(ev);
+    kill(e->ev_int); kill(e->ev_emit);
     kill(e->ev_join); kill(e->ev_pk0); kill(e->ev_pk1); kill(e->ev_warp); kill(e->ev_idx); kill(e->ev_peaks);
     for (int i = 0; i < 4; i++) { kill(e->ev_klt[i]); kill(e->ev_g4[i]); }
     for (auto &row : e->tr_ev) for (auto &ev : row) kill(ev);
@@ -750,6 +753,12 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             e->peaks_after_int = kv ? atoi(kv) : (B >= 256 ? 1 : 0);
             const char *wv = getenv("ROAM_WARP_AFTER_INTEGRAL");
             e->warp_after_int = wv ? atoi(wv) : 0;
+            // ... and not for the determinants' end itself but for the first two kernels of the bookkeeping behind them (candidate order,
+            // longest-list-first ordering: 18 us + 0.6 ms alone): launched at the same moment as the pyramid's and the peaks' 130 000
+            // workgroups, whichever bookkeeping kernel came first waited ~3.8 ms for slots.  +0.8 % (52.6-52.8 -> 53.1-53.3 k, same box;
+            // the pyramid alone behind that event: nothing; the peaks alone: -1 %).  ROAM_PYR_AFTER_EMIT / ROAM_PEAKS_AFTER_EMIT = 0: as before
+            e->pyr_after_emit = getenv("ROAM_PYR_AFTER_EMIT") ? atoi(getenv("ROAM_PYR_AFTER_EMIT")) : (B >= 256 ? 1 : 0);
+            e->peaks_after_emit = getenv("ROAM_PEAKS_AFTER_EMIT") ? atoi(getenv("ROAM_PEAKS_AFTER_EMIT")) : (B >= 256 ? 1 : 0);
             if (e->warp_after_int && !e->pyr_after_int) e->pyr_after_int = 1;     // (the event is made for either)
             r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
         }
@@ -1358,7 +1367,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipStream_t sP = ctx->stream5;
     HIP_TRY(ctx, hipEventRecord(e->ev_idx, sA));
     HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_idx, 0));
-    if (e->peaks_after_int && e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_int, 0));
+    if (e->peaks_after_int && e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sP, (e->peaks_after_emit && e->ev_emit) ? e->ev_emit : e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[0], sP));
@@ -1373,7 +1382,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[2], sA));
     HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
     HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
-    if (e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_int, 0));
+    if (e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sB, (e->pyr_after_emit && e->ev_emit) ? e->ev_emit : e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[3], sB));
     HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B, e->pyr_dark));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[4], sB));
@@ -1428,7 +1437,8 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         // keyframe refresh, on the device
         e->rt.res = res_slot;
         if (e->pyr_after_int && !e->ev_int) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_int, hipEventDisableTiming));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1));
+        if ((e->pyr_after_emit || e->peaks_after_emit) && e->pyr_after_int && !e->ev_emit && B >= 256) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_emit, hipEventDisableTiming));
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1, e->ev_emit));
         if (e->pyr_after_int) e->ev_int_valid = true;
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }

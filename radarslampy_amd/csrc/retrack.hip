@@ -2013,7 +2013,7 @@ static hipError_t launch_det(hipStream_t st, const RtArgs &a, int first, int P)
     return hipGetLastError();
 }
 
-hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace, hipEvent_t after_integral, int after_det)
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace, hipEvent_t after_integral, int after_det, hipEvent_t after_emit)
 {
     const int W = a.W, R = a.slots;
     // image-scale kernels chunk by chunk (the float64 integral images of `slots` detections are resident at once); the
@@ -2048,6 +2048,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {
         hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
+        static const int emit_where = getenv("ROAM_EMIT_EVENT_WHERE") ? atoi(getenv("ROAM_EMIT_EVENT_WHERE")) : 0;     // 0 after rt_emit, 1 after the ordering, 2 after the small bookkeeping class
+        if (after_emit && emit_where == 0 && (e = hipEventRecord(after_emit, st)) != hipSuccess) return e;       // (a front-end kernel of a later step may wait for it)
         // the bookkeeping is one latency-bound wavefront per detection and its time grows with the candidate list: longest lists first
         // (in the default step 2.1 -> ... ms for the kernel; the work is the same, the tail is not)
         RtArgs ab = a;
@@ -2056,7 +2058,9 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
             if ((e = launch_order_by_count(st, a.cand_n, B, BP_MAX_PTS, a.blob_order_buf, 1)) != hipSuccess) return e;
             ab.blob_order = a.blob_order_buf;
         }
+        if (after_emit && emit_where == 1 && (e = hipEventRecord(after_emit, st)) != hipSuccess) return e;
         hipLaunchKernelGGL(rt_blobs_kernel<true>, dim3(B), dim3(64), 0, st, ab, 0);
+        if (after_emit && emit_where == 2 && (e = hipEventRecord(after_emit, st)) != hipSuccess) return e;
         hipLaunchKernelGGL(rt_blobs_kernel<false>, dim3(B), dim3(64), 0, st, ab, 0);
         e = launch_ssc_batch(st, a.kp, (int64_t)BP_MAX_PTS * 3, a.kp_n, BP_MAX_PTS, B, 200, 0.1, W, W, a.ssc_work, a.sel, a.sel_n, a.rt_n, 0);
         if (e != hipSuccess) return e;
