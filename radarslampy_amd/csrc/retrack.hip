@@ -2048,7 +2048,7 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else {
         hipLaunchKernelGGL(rt_emit_kernel, dim3(B), dim3(256), 0, st, a, 0);
-        static const int emit_where = getenv("ROAM_EMIT_EVENT_WHERE") ? atoi(getenv("ROAM_EMIT_EVENT_WHERE")) : 0;     // 0 after rt_emit, 1 after the ordering, 2 after the small bookkeeping class
+        static const int emit_where = getenv("ROAM_EMIT_EVENT_WHERE") ? atoi(getenv("ROAM_EMIT_EVENT_WHERE")) : 1;     // 0 after rt_emit, 1 after the ordering (default), 2 after the small bookkeeping class
         if (after_emit && emit_where == 0 && (e = hipEventRecord(after_emit, st)) != hipSuccess) return e;       // (a front-end kernel of a later step may wait for it)
         // the bookkeeping is one latency-bound wavefront per detection and its time grows with the candidate list: longest lists first
         // (in the default step 2.1 -> ... ms for the kernel; the work is the same, the tail is not)
