@@ -297,7 +297,11 @@ __global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
 #define RI_PHASE_SKIP 1                     // walk the list of phases that matter (retrack_build_phases) instead of all bands x groups
 #endif
 #define RI_PHL_MAX 1024                     // phases of the largest image of the one-sweep kernel (128 bands x 8 groups)
-#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * 65 * 8 + RI_LDS_PAD)
+#ifndef RI_BD
+#define RI_BD 4                             // batches of eight columns the row wave reads ahead of its chain
+#endif
+#define RI_TP 66                            // tile pitch in doubles: even, so that the row wave moves two columns per LDS instruction (round 6)
+#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * RI_TP * 8 + RI_LDS_PAD)
 #ifndef RI_BOX
 #define RI_BOX 2560                         // (round 6: 1536 -> 2560, the LDS that is left at two workgroups per CU: fewer patches on the gather path, -2 %)
 #endif
@@ -328,12 +332,27 @@ __global__ __launch_bounds__(64) void rt_boxtab_kernel(const uint32_t *__restric
     }
 }
 
+#ifdef RI_PROF
+__device__ unsigned long long ri_prof[16];
+extern "C" int roam_debug_integral_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ri_prof), sizeof(ri_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ri_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define RI_P(k) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); rip_[k] += tn_ - rit_; rit_ = tn_; }
+#else
+#define RI_P(k)
+#endif
 __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs a, int first)
 {
-    extern __shared__ double ri_lds[];
+#ifdef RI_PROF
+    unsigned long long rip_[8] = {0}, rit_ = __builtin_amdgcn_s_memtime();
+#endif
+    extern __shared__ __align__(16) double ri_lds[];
     const int ls = blockIdx.x, slot = first + ls;
     if (slot >= *a.rt_n || !rt_one_sweep(a, first) || a.fused) return;
-    typedef double Tile[RI_ROWS][65];
+    typedef double Tile[RI_ROWS][RI_TP];
     Tile *tiles = reinterpret_cast<Tile *>(ri_lds);                        // [2][RI_WAVES]
     const int W = a.W, H = a.W, t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int nbands = (H + RI_ROWS - 1) / RI_ROWS;
@@ -547,9 +566,13 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
 #pragma unroll 1
             for (int i = 0; i < nph; i++) {
                 const int e_4 = ph_ent(i + 4);                             // (lands while this phase runs)
+                RI_P(0)
                 __syncthreads();                                           // A(i) and B(i-1) are complete
+                RI_P(1)
                 if (i > 0) C(i - 1, e_m1);
-                if (i + 1 < nph) { A1(i + 1, e_2, e_3); A2(i + 1, ph_band(e_1), ph_group(e_1)); }
+                RI_P(2)
+                if (i + 1 < nph) { A1(i + 1, e_2, e_3); RI_P(3) A2(i + 1, ph_band(e_1), ph_group(e_1)); }
+                RI_P(4)
                 e_m1 = e_0; e_0 = e_1; e_1 = e_2; e_2 = e_3; e_3 = e_4;
             }
         }
@@ -557,6 +580,8 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         if (nph > 0) C(nph - 1, e_m1);
     } else {
         // ------------------------------------------------------------------------------------ the row wave: B(i)
+        // (s_setprio 3 for this wave - the chain a phase waits for - moves the wait from the column waves' barrier to their taps: the row wave
+        // busy 80 -> 70 % of a phase, the column waves' A1 55 -> 67 %, the kernel 6.44 -> 6.43 ms per 512: dropped)
         double carry = 0.0;                                                // running sum of row band * RI_ROWS + lane
         int pband = -1;
         int e_nx = ph_ent(0);
@@ -565,36 +590,45 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             e_nx = ph_ent(i + 1);
             if (band != pband) { carry = 0.0; pband = band; }              // (the phases a band leaves out on its left have sums of zero)
             const bool live = lane < RI_ROWS && band * RI_ROWS + lane < H;
+            RI_P(5)
             __syncthreads();
+            RI_P(6)
             if (live) {
                 const int C0 = g * 64 * RI_WAVES, ncols = min(64 * RI_WAVES, W - C0);
                 Tile *tg = tiles + (i & 1) * RI_WAVES;
                 int j = 0;
                 if (ncols >= 16) {
-                    // two batches of eight columns in flight: while one is added up (eight dependent float64 additions) and written
-                    // back, the reads of the other have a whole batch to land (one batch ahead, every batch waited for its own LDS
-                    // round trip: 52 cycles per column)
-                    double xa[8], xb[8];
+                    // batches of eight columns (eight dependent float64 additions), 16-byte LDS accesses (two columns per instruction)
                     auto rd = [&](double(&x)[8], int jj) {                 // (a batch never straddles two tiles: 64 = 8 x 8)
-                        const double *q = &tg[jj >> 6][lane][jj & 63];
+                        const double2 *q = reinterpret_cast<const double2 *>(&tg[jj >> 6][lane][jj & 63]);
 #pragma unroll
-                        for (int u = 0; u < 8; u++) x[u] = q[u];
+                        for (int u = 0; u < 4; u++) { const double2 v2 = q[u]; x[2 * u] = v2.x; x[2 * u + 1] = v2.y; }
                     };
                     auto chain_wr = [&](double(&x)[8], int jj) {
 #pragma unroll
                         for (int u = 0; u < 8; u++) { carry = __dadd_rn(carry, x[u]); x[u] = carry; }
-                        double *q = &tg[jj >> 6][lane][jj & 63];
+                        double2 *q = reinterpret_cast<double2 *>(&tg[jj >> 6][lane][jj & 63]);
 #pragma unroll
-                        for (int u = 0; u < 8; u++) q[u] = x[u];
+                        for (int u = 0; u < 4; u++) q[u] = make_double2(x[2 * u], x[2 * u + 1]);
                     };
-                    rd(xa, 0);
-                    rd(xb, 8);
-                    for (; j + 16 <= ncols; j += 16) {
-                        chain_wr(xa, j);
-                        if (j + 24 <= ncols) rd(xa, j + 16);
-                        chain_wr(xb, j + 8);
-                        if (j + 32 <= ncols) rd(xb, j + 24);
+                    // RI_BD batches of eight columns are in flight ahead of the chain: beside eight column waves' tap reads an LDS read
+                    // takes several hundred cycles to come back, and one batch ahead the chain waited for it at every batch
+                    // (56 cycles per column, the row wave busy 87 % of a phase: profiles/ri_prof.py)
+                    double xr[RI_BD][8];
+#pragma unroll
+                    for (int u = 0; u < RI_BD; u++)
+                        if (8 * u + 8 <= ncols) rd(xr[u], 8 * u);
+                    for (; j + 8 * RI_BD <= ncols; j += 8 * RI_BD) {
+#pragma unroll
+                        for (int u = 0; u < RI_BD; u++) {
+                            chain_wr(xr[u], j + 8 * u);
+                            if (j + 8 * (RI_BD + u) + 8 <= ncols) rd(xr[u], j + 8 * (RI_BD + u));
+                        }
                     }
+                    // (what is left of the group - fewer than RI_BD batches - is in the registers already)
+#pragma unroll
+                    for (int u = 0; u < RI_BD; u++)
+                        if (j + 8 <= ncols) { chain_wr(xr[u], j); j += 8; }
                 }
                 for (; j < ncols; j++) {
                     double *q = &tg[j >> 6][lane][j & 63];
@@ -605,6 +639,9 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         }
         __syncthreads();
     }
+#ifdef RI_PROF
+    if (lane == 0 && (wave == 0 || wave == RI_WAVES)) for (int k = 0; k < 8; k++) atomicAdd(&ri_prof[k + (wave == 0 ? 0 : 8)], rip_[k]);
+#endif
 }
 
 // A maximum goes straight onto the detection's candidate list, in whatever order the workgroups get there; rt_emit_kernel sorts the
