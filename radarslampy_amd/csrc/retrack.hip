@@ -491,7 +491,13 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                         const float wx1 = __fmul_rn((float)((mk >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
                         const float wy1 = __fmul_rn((float)(mk >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
                         const uint8_t *q = bx + (iy - mny) * bp + (ix - mnx);
+#ifdef RI_TAP16
+                        // (experiment: the two neighbouring codes of a polar row in ONE 16-bit LDS read at any alignment)
+                        const uint32_t w0 = reinterpret_cast<const RtU16 *>(q)->v, w1 = reinterpret_cast<const RtU16 *>(q + bp)->v;
+                        const float s00 = lut[w0 & 255], s01 = lut[w0 >> 8], s10 = lut[w1 & 255], s11 = lut[w1 >> 8];
+#else
                         const float s00 = lut[q[0]], s01 = lut[q[1]], s10 = lut[q[bp]], s11 = lut[q[bp + 1]];   // lut[0] = 0: bins past the scan
+#endif
                         r_ = __fmul_rn(s00, __fmul_rn(wy0, wx0));
                         r_ = __fadd_rn(r_, __fmul_rn(s01, __fmul_rn(wy0, wx1)));
                         r_ = __fadd_rn(r_, __fmul_rn(s10, __fmul_rn(wy1, wx0)));
