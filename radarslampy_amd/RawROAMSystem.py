@@ -85,13 +85,15 @@ def default_decode_workers():
 
 
 def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows=400, stride=3779, payload_off=11, clip=2025,
-                   synchronous=False, on_engine=None, after_step=None, before_close=None, records_pinned=False):
+                   synchronous=False, on_engine=None, after_step=None, before_close=None, records_pinned=False, timing=None):
     """records: iterator of n_frames (rows, stride) u8 Oxford records of ONE sequence.  -> (poses (n_frames-1, 3), per-pair log).
     Frame 0 seeds the lane (features detected on the device); frame k is uploaded LOOKAHEAD frames before step k needs it.
     synchronous=True awaits every pose before the next frame is stepped (the latency of one pair instead of the pipeline's
     rate; same poses) and also returns the per-pair seconds from the step call to the pose on the host.
     records_pinned: every record is a view of pinned memory that stays untouched for RING more frames (NativeRecordReader(hold=RING)):
     it is uploaded from where it lies instead of through this function's staging ring.
+    timing: a dict that receives `loop_s` - the seconds from the first step's enqueue to the last pose on the host (the engine's creation,
+    the first uploads and the first frame's detection before it, the tear-down after it: what a sequence of any length pays once).
     Hooks (the multi-GPU keyframe exchange of BASELINE config 5 lives in them): on_engine(eng) once after the engine exists,
     after_step(eng, k) after every enqueued step, before_close(eng) when all poses are in."""
     flags = dict(paramFlags or {})
@@ -177,6 +179,8 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
         eng.synchronize()
         eng.init_lane_detect(0, 0, init_pose)
         lat = []
+        import time as _time
+        t_loop = _time.perf_counter()
         for k in range(1, n_frames):
             if synchronous:
                 import time
@@ -195,6 +199,8 @@ def stream_records(records, n_frames, init_pose, paramFlags=None, ctx=None, rows
         if not synchronous:
             for s in range(max(0, n_frames - 1 - LAG), n_frames - 1):
                 collect(s)
+        if timing is not None:
+            timing["loop_s"] = _time.perf_counter() - t_loop
         if before_close is not None:
             before_close(eng)
     finally:

@@ -803,13 +803,8 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP;
         }
     e->ev_ok = true;
-    for (auto &row : e->tr_ev)
-        for (auto &ev : row)
-            if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
-    if (e->rt_on)
-        for (auto &row : e->rt_ev)
-            for (auto &ev : row)
-                if (hipEventCreate(&ev) != hipSuccess) { ROAM_SET_ERR(ctx, "hipEventCreate failed"); roam_engine_destroy(ctx); return ROAM_E_HIP; }
+    // (the 64 x (6 + 3 x RT_TRACE_CHUNKS) timestamp events of the per-step traces are created by the first step that records into a slot:
+    // creating all of them here was ~5 ms of the 13.6 ms a single sequence's engine cost to set up and tear down, recorded or not)
     e->tr_ok = true;
     HIP_TRY(ctx, launch_warp_map(ctx->stream, cfg->rows, cfg->clip, e->warp_map));
     HIP_TRY(ctx, launch_pyr_dark(ctx->stream, e->warp_map, e->W, e->W, cfg->clip, e->pyr_dark));
@@ -817,7 +812,10 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
     if (e->rt_on) HIP_TRY(ctx, launch_retrack_darktab(ctx->stream, e->warp_map, e->W, cfg->clip, const_cast<uint32_t *>(e->rt.darktab)));
     if (e->rt_on && e->rt.fused) { const int32_t rc_ = fused_tables(ctx, e); if (rc_ != ROAM_OK) { roam_engine_destroy(ctx); return rc_; } }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (e->rt_on && e->W <= 2048) {
+    e->rt_image_px = (int64_t)e->W * e->W;
+    if (e->rt_on && e->W <= 2048 && B >= RT_TWO_PASS_SLOTS) {
+        e->rt_image_px = 0;
+        // (an engine of fewer lanes never launches the one-sweep kernel: a single sequence's engine skips these ~5 ms of its set-up)
         // the phases the one-sweep integral kernel walks: from the sampling map and the dark-step table just made (host code, once)
         // (through PINNED staging: a pageable hipMemcpy of this size leaves the runtime in a state in which the small device-to-device
         // copy of the keyframe exchange costs 80 us more per step - measured, round 6)
@@ -1361,6 +1359,10 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     for (int b = 0; b < B; b++) { hs[b] = scan_idx[b] & ~ROAM_STEP_NEW_SEQUENCE; hs[B + b] = (scan_idx[b] & ROAM_STEP_NEW_SEQUENCE) ? 1 : 0; }
     HIP_TRY(ctx, hipMemcpyAsync(e->scan_idx[pb], hs, sizeof(int32_t) * 2 * (size_t)B, hipMemcpyHostToDevice, sA));
     hipEvent_t *tr = e->tr_ev[e->nstep & 63];
+    if (e->stage_ev) {
+        for (auto &ev : e->tr_ev[e->nstep & 63]) if (!ev) HIP_TRY(ctx, hipEventCreate(&ev));
+        if (e->rt_on) for (auto &ev : e->rt_ev[e->nstep & 63]) if (!ev) HIP_TRY(ctx, hipEventCreate(&ev));
+    }
     e->tr_ev_ok[e->nstep & 63] = e->stage_ev;       // (the switch may be flipped between steps: every step remembers what it recorded)
     if (e->stage_ev) e->stage_ev_step = e->nstep;
     // the peak kernel gets its own stream: it only needs the scan indices (event ev_idx) and is joined before g4
