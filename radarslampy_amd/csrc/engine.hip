@@ -123,6 +123,9 @@ struct Engine {
     hipEvent_t ev_int = nullptr;                    // after the integral images of a step's (first) detection chunk
     hipEvent_t ev_emit = nullptr;                   // after the first bookkeeping kernels behind the determinants (ROAM_PYR_AFTER_EMIT / ROAM_PEAKS_AFTER_EMIT)
     int pyr_after_emit = 0, peaks_after_emit = 0;
+    hipEvent_t ev_emit2[2] = {};                    // the same moment, alternating between consecutive steps (ROAM_SWAP_WARP_PYR: the warp of step N + 2 waits for step N's)
+    int swap_warp_pyr = 0;
+    hipEvent_t ev_emit_last = nullptr;              // (swap experiment) the event the last step recorded there
     bool ev_int_valid = false;
     int warp_after_int = 0;                         // ROAM_WARP_AFTER_INTEGRAL (experiment)
     int peaks_after_int = 0;                        // ROAM_PEAKS_AFTER_INTEGRAL (experiment): the peak kernel waits for the same event as the pyramid
@@ -590,7 +593,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     // every event handle starts out null, so a creation that failed half way leaks nothing
     auto kill = [](hipEvent_t &ev) { if (ev) { hipEventDestroy(ev); ev = nullptr; } };
     for (auto &ev : e->ev) kill(ev);
-    kill(e->ev_int); kill(e->ev_emit);
+    kill(e->ev_int); kill(e->ev_emit); kill(e->ev_emit2[0]); kill(e->ev_emit2[1]);
     kill(e->ev_join); kill(e->ev_pk0); kill(e->ev_pk1); kill(e->ev_warp); kill(e->ev_idx); kill(e->ev_peaks);
     for (int i = 0; i < 4; i++) { kill(e->ev_klt[i]); kill(e->ev_g4[i]); }
     for (auto &row : e->tr_ev) for (auto &ev : row) kill(ev);
@@ -759,6 +762,9 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             // the pyramid alone behind that event: nothing; the peaks alone: -1 %).  ROAM_PYR_AFTER_EMIT / ROAM_PEAKS_AFTER_EMIT = 0: as before
             e->pyr_after_emit = getenv("ROAM_PYR_AFTER_EMIT") ? atoi(getenv("ROAM_PYR_AFTER_EMIT")) : (B >= 256 ? 1 : 0);
             e->peaks_after_emit = getenv("ROAM_PEAKS_AFTER_EMIT") ? atoi(getenv("ROAM_PEAKS_AFTER_EMIT")) : (B >= 256 ? 1 : 0);
+            // (experiment) the warp and the pyramid trade places: the warp of step N + 2 beside step N's bookkeeping, the pyramid of step
+            // N + 1 beside step N's back end (after its tracker)
+            e->swap_warp_pyr = getenv("ROAM_SWAP_WARP_PYR") ? atoi(getenv("ROAM_SWAP_WARP_PYR")) : 0;
             if (e->warp_after_int && !e->pyr_after_int) e->pyr_after_int = 1;     // (the event is made for either)
             r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
         }
@@ -1369,7 +1375,7 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     hipStream_t sP = ctx->stream5;
     HIP_TRY(ctx, hipEventRecord(e->ev_idx, sA));
     HIP_TRY(ctx, hipStreamWaitEvent(sP, e->ev_idx, 0));
-    if (e->peaks_after_int && e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sP, (e->peaks_after_emit && e->ev_emit) ? e->ev_emit : e->ev_int, 0));
+    if (e->peaks_after_int && e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sP, (e->swap_warp_pyr && e->ev_emit_last) ? e->ev_emit_last : (e->peaks_after_emit && e->ev_emit) ? e->ev_emit : e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_PEAKS], sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev_pk0, sP));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[0], sP));
@@ -1379,11 +1385,15 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[5], sP));
     HIP_TRY(ctx, hipEventRecord(e->ev_peaks, sP));
     if (e->warp_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_int, 0));
+    if (e->swap_warp_pyr && e->nstep >= 2 && e->ev_emit2[e->nstep & 1] && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sA, e->ev_emit2[e->nstep & 1], 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[1], sA));
     HIP_TRY(ctx, launch_warp_gather(sA, e->warp_map, pool_warp_src(e, e->scan_idx[pb]), B, c.rows, c.clip, next, e->pd.lane_stride, e->warp_dark_zero));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[2], sA));
     HIP_TRY(ctx, hipEventRecord(e->ev_warp, sA));                         // end of stage A
     HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_warp, 0));
+    if (e->swap_warp_pyr) {
+        if (e->nstep >= 1) HIP_TRY(ctx, hipStreamWaitEvent(sB, e->ev_klt[(e->nstep + 3) & 3], 0));      // the tracker of the step before this one
+    } else
     if (e->pyr_after_int && e->ev_int_valid) HIP_TRY(ctx, hipStreamWaitEvent(sB, (e->pyr_after_emit && e->ev_emit) ? e->ev_emit : e->ev_int, 0));
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(tr[3], sB));
     HIP_TRY(ctx, launch_build_pyramid(sB, next, e->pd, B, e->pyr_dark));
@@ -1440,7 +1450,14 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         e->rt.res = res_slot;
         if (e->pyr_after_int && !e->ev_int) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_int, hipEventDisableTiming));
         if ((e->pyr_after_emit || e->peaks_after_emit) && e->pyr_after_int && !e->ev_emit && B >= 256) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_emit, hipEventDisableTiming));
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1, e->ev_emit));
+        if (e->swap_warp_pyr && e->pyr_after_int && B >= 256) {
+            // (swap experiment: the "first bookkeeping kernels are out" event alternates between two objects, so that a wait enqueued two
+            // steps later still finds this step's record; ev_emit is made to point at the one just recorded for the peaks' wait)
+            if (!e->ev_emit2[e->nstep & 1]) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_emit2[e->nstep & 1], hipEventDisableTiming));
+        }
+        hipEvent_t emit_ev = (e->swap_warp_pyr && e->ev_emit2[e->nstep & 1]) ? e->ev_emit2[e->nstep & 1] : e->ev_emit;
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1, emit_ev));
+        if (e->swap_warp_pyr) e->ev_emit_last = emit_ev;
         if (e->pyr_after_int) e->ev_int_valid = true;
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
     }
