@@ -77,6 +77,7 @@ struct Engine {
     double *T_wj0 = nullptr, *T_init = nullptr, *p_w = nullptr, *p_jt = nullptr;
     double *lm_work = nullptr, *lm_out = nullptr;
     int32_t *lm_nfev = nullptr, *lm_info = nullptr;
+    hipEvent_t ev_lm[2] = {};            // fork / join of the LM's workgroup form on the peaks' stream (batches)
     int32_t *lm_big = nullptr;           // MdsProblemDesc::big: the solves left to the workgroup form, two alternating lists
     int lm_big_slot = 0;
     roam_lane_result *results = nullptr;           // ring of RES_RING per-step records (RES_RING x B)
@@ -125,6 +126,7 @@ struct Engine {
     int pyr_after_emit = 0, peaks_after_emit = 0;
     hipEvent_t ev_emit2[2] = {};                    // the same moment, alternating between consecutive steps (ROAM_SWAP_WARP_PYR: the warp of step N + 2 waits for step N's)
     int swap_warp_pyr = 0;
+    int lm_side = 0;                                // ROAM_LM_SIDE=1 (experiment): the LM's workgroup form on the peaks' stream beside the wave form instead of behind it
     hipEvent_t ev_emit_last = nullptr;              // (swap experiment) the event the last step recorded there
     bool ev_int_valid = false;
     int warp_after_int = 0;                         // ROAM_WARP_AFTER_INTEGRAL (experiment)
@@ -593,7 +595,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     // every event handle starts out null, so a creation that failed half way leaks nothing
     auto kill = [](hipEvent_t &ev) { if (ev) { hipEventDestroy(ev); ev = nullptr; } };
     for (auto &ev : e->ev) kill(ev);
-    kill(e->ev_int); kill(e->ev_emit); kill(e->ev_emit2[0]); kill(e->ev_emit2[1]);
+    kill(e->ev_int); kill(e->ev_emit); kill(e->ev_emit2[0]); kill(e->ev_emit2[1]); kill(e->ev_lm[0]); kill(e->ev_lm[1]);
     kill(e->ev_join); kill(e->ev_pk0); kill(e->ev_pk1); kill(e->ev_warp); kill(e->ev_idx); kill(e->ev_peaks);
     for (int i = 0; i < 4; i++) { kill(e->ev_klt[i]); kill(e->ev_g4[i]); }
     for (auto &row : e->tr_ev) for (auto &ev : row) kill(ev);
@@ -765,6 +767,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             // (experiment) the warp and the pyramid trade places: the warp of step N + 2 beside step N's bookkeeping, the pyramid of step
             // N + 1 beside step N's back end (after its tracker)
             e->swap_warp_pyr = getenv("ROAM_SWAP_WARP_PYR") ? atoi(getenv("ROAM_SWAP_WARP_PYR")) : 0;
+            e->lm_side = getenv("ROAM_LM_SIDE") ? atoi(getenv("ROAM_LM_SIDE")) : 0;      // (measured: nothing - 70.68 / 70.46 against 70.69 / 70.29 ms per step)
             if (e->warp_after_int && !e->pyr_after_int) e->pyr_after_int = 1;     // (the event is made for either)
             r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
         }
@@ -1434,6 +1437,10 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
         P.N = KM; P.nstride = KS; P.nmax = KM; P.B = B; P.period = 0.25;
         for (int i = 0; i < 5; i++) P.sigma5[i] = c.sigma5[i];
         P.big = e->lm_big; P.big_slot = e->lm_big_slot; e->lm_big_slot ^= 1;
+        if (e->lm_side) {                                                    // batches: the workgroup form beside the wave form (the peaks' stream is idle here)
+            if (!e->ev_lm[0]) { HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_lm[0], hipEventDisableTiming)); HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_lm[1], hipEventDisableTiming)); }
+            P.side = ctx->stream5; P.ev_fork = e->ev_lm[0]; P.ev_join = e->ev_lm[1];
+        }
         HIP_TRY(ctx, launch_mds_solve(st, P, e->lm_work, e->lm_out, e->lm_nfev, e->lm_info, nullptr, nullptr));
     }
     if (e->stage_ev) HIP_TRY(ctx, hipEventRecord(e->ev[ST_GLUE], st));

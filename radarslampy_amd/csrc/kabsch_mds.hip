@@ -621,24 +621,40 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     // at once from the other's problems.  ROAM_LM_BLOCK=1 keeps the workgroup form for everything (A/B).
     static const bool block_form = getenv("ROAM_LM_BLOCK") != nullptr && atoi(getenv("ROAM_LM_BLOCK")) != 0;
     int wave_rows = 0;                                // N + 2 <= wave_rows: the wave kernel's
+    static const int wpe_env = getenv("ROAM_LM_WPE") ? atoi(getenv("ROAM_LM_WPE")) : 0;
+    const int wpe = wpe_env == 1 ? 1 : 2;
+    MdsProblemDesc pw = p;
+    hipStream_t st_block = st;
+    bool join = false;
     if (!block_form) {
         const int ppt = std::min(4, (p.nmax + 2 + 63) / 64);
         wave_rows = 64 * ppt;
+        const bool both = p.nmax + 2 > wave_rows;
+        // a batch's workgroup form BESIDE the wave form, on the caller's side stream: behind it, the few problems above 254 points were
+        // 1.3 ms of the back end's chain in every step (each is a 0.5 ms latency chain whatever their number)
+        if (both && p.side && p.ev_fork && p.ev_join) {
+            pw.big = nullptr;
+            hipError_t ef = hipEventRecord(p.ev_fork, st);
+            if (ef == hipSuccess) ef = hipStreamWaitEvent(p.side, p.ev_fork, 0);
+            if (ef != hipSuccess) return ef;
+            st_block = p.side;
+            join = true;
+        }
         // register budget: two wavefronts per SIMD (<= 256 registers; the solve wants ~290).  4 096 solves alone: 1.46-1.93 ms against
         // 1.93-2.51 unconstrained (one wave per SIMD), 1.9-2.4 at three, 2.1-2.7 at four, 3.56-4.48 for the workgroup form; a lone
         // solve is as fast either way (profiles/r06_lm_experiments.txt).  ROAM_LM_WPE=1: unconstrained (A/B)
-        static const int wpe_env = getenv("ROAM_LM_WPE") ? atoi(getenv("ROAM_LM_WPE")) : 0;
-        const int wpe = wpe_env == 1 ? 1 : 2;
-#define LMW_LAUNCH(PPT_, WPE_) hipLaunchKernelGGL((mds_lm_wave_kernel<PPT_, WPE_>), dim3(p.B), dim3(64), 0, st, p, out6, nfev, info, x0_out, r0_out)
+#define LMW_LAUNCH(PPT_, WPE_) hipLaunchKernelGGL((mds_lm_wave_kernel<PPT_, WPE_>), dim3(p.B), dim3(64), 0, st, pw, out6, nfev, info, x0_out, r0_out)
 #define LMW_LAUNCH_W(PPT_) { if (wpe == 2) LMW_LAUNCH(PPT_, 2); else LMW_LAUNCH(PPT_, 1); }
-        switch (ppt) {
-        case 1: LMW_LAUNCH_W(1) break;
-        case 2: LMW_LAUNCH_W(2) break;
-        case 3: LMW_LAUNCH_W(3) break;
-        default: LMW_LAUNCH_W(4) break;
+        if (!join) {
+            switch (ppt) {
+            case 1: LMW_LAUNCH_W(1) break;
+            case 2: LMW_LAUNCH_W(2) break;
+            case 3: LMW_LAUNCH_W(3) break;
+            default: LMW_LAUNCH_W(4) break;
+            }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess || !both) return e;
         }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess || p.nmax + 2 <= wave_rows) return e;
     }
     const size_t mmax = 2 * (size_t)p.nmax + 3;
     size_t need = (mmax * 9 + p.nmax) * sizeof(double);
@@ -650,9 +666,14 @@ hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *wor
     // (workgroup barriers degenerate to no-ops, reductions stay in registers) has the lowest latency
     const int threads = p.nmax <= 192 ? 64 : (p.nmax <= 448 ? 128 : LM_TMAX);
     static const int big_grid = getenv("ROAM_LM_BIG_GRID") ? atoi(getenv("ROAM_LM_BIG_GRID")) : 512;
-    const int grid = (p.big && wave_rows) ? std::min(p.B, big_grid) : p.B;
-    hipLaunchKernelGGL(mds_lm_kernel, dim3(grid), dim3(threads), lds, st, p, work, out6, nfev, info, x0_out, r0_out, (int)lds, wave_rows);
-    return hipGetLastError();
+    const int grid = (pw.big && wave_rows) ? std::min(p.B, big_grid) : p.B;
+    hipLaunchKernelGGL(mds_lm_kernel, dim3(grid), dim3(threads), lds, st_block, pw, work, out6, nfev, info, x0_out, r0_out, (int)lds, wave_rows);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !join) return e;
+    if ((e = hipEventRecord(p.ev_join, st_block)) != hipSuccess) return e;
+    LMW_LAUNCH_W(4)                                   // (both forms are needed: the bound is above 254 points, four slots)
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipStreamWaitEvent(st, p.ev_join, 0);
 }
 
 __global__ __launch_bounds__(256) void mds_undistort_kernel(const double *__restrict__ v3, const double *__restrict__ pts,

@@ -150,6 +150,10 @@ struct MdsProblemDesc {
     // two slots of 1 + B ints (count, problem ids), zero on first use; big_slot alternates between consecutive solves of a stream
     int32_t *big = nullptr;
     int big_slot = 0;
+    // optional (engine, batches): the workgroup form runs on `side` BESIDE the wave form instead of behind it (both forms skip each other's
+    // problems; no list then): fork / join events of the caller
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 // work: B x ((2*nmax+3) x 9 + nmax) doubles; out6: B x 6; nfev/info: B; x0/r0 optional
 hipError_t launch_mds_solve(hipStream_t st, const MdsProblemDesc &p, double *work, double *out6,
