@@ -196,7 +196,10 @@ hipError_t launch_warp_map(hipStream_t st, int rows, int cols, uint32_t *map)
 #endif
 #define WG_TW 64          // tile width  (one wavefront = 64 consecutive pixels of a row)
 #define WG_TH 16          // tile height
-#define WG_BOX_ELEMS 4096     // polar samples staged per pass, already decoded to float32 (16 KB)
+#define WG_BOX_ELEMS 4096     // polar samples staged per pass, already decoded to float32 (16 KB; WG_CELL: twice that)
+#ifndef WG_CELL
+#define WG_CELL 0             // (round 6 experiment) the box as CELLS {s[k][c], s[k+1][c]}: the four taps of a pixel are two neighbouring cells - ONE ds_read2_b64
+#endif
 #ifndef WG_FILL_U
 #define WG_FILL_U 4       // scans whose box rows are loaded before the first load is consumed
 #endif
@@ -225,7 +228,7 @@ template <int M> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
 // written with one 16-byte LDS store (the LDS row pitch bp is a multiple of 4 floats).  wave wvs takes the row
 // groups wvs, wvs+4, ...; the U scans' loads are issued before the first is consumed.
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
-template <int U, bool CHK, bool RAWK = false>
+template <int U, bool CHK, bool RAWK = false, bool CELL = false>
 __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t lane_stride,
                                          const int32_t *__restrict__ lane_index, int l, int64_t row_stride, int rows,
                                          int cols, int mnx, int mny, int bw, int bp, int bh, int elems, int wvs, int lane,
@@ -258,6 +261,12 @@ __device__ __forceinline__ void box_fill(const uint8_t *__restrict__ sp, int64_t
                 v.y = (!CHK || x0 + 1 < cols) ? (RAWK ? (float)((raw[u] >> 8) & 255u) : code_to_f32((raw[u] >> 8) & 255u)) : 0.f;
                 v.z = (!CHK || x0 + 2 < cols) ? (RAWK ? (float)((raw[u] >> 16) & 255u) : code_to_f32((raw[u] >> 16) & 255u)) : 0.f;
                 v.w = (!CHK || x0 + 3 < cols) ? (RAWK ? (float)(raw[u] >> 24) : code_to_f32(raw[u] >> 24)) : 0.f;
+                if (CELL) {
+                    // sample (k, c) is the upper half of cell (k, c) and the lower half of cell (k - 1, c): two ds_write2_b32 each
+                    float *d = bq + 2 * (k * bp + c) + u * 2 * elems;
+                    d[0] = v.x; d[2] = v.y; d[4] = v.z; d[6] = v.w;
+                    if (k > 0) { float *e = d - 2 * bp + 1; e[0] = v.x; e[2] = v.y; e[4] = v.z; e[6] = v.w; }
+                } else
                 if (pp) {                                 // (4-byte aligned only: four dword stores; the slot before a 32-sample block repeats its first sample)
                     float *d = drow + u * elems;
                     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
                                                           int cols, int W, uint8_t *__restrict__ cart_u8,
                                                           int64_t u8_lane_stride, int gx, int gy, int total, int dark_stays_zero)
 {
-    __shared__ __align__(16) float box[WG_BOX_ELEMS];
+    __shared__ __align__(16) float box[WG_BOX_ELEMS * (WG_CELL ? 2 : 1)];
     __shared__ int red[4][4];
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own
     // L2), so XCD x is given the x-th contiguous eighth of the (scan group, tile row, tile) list:
@@ -539,9 +548,9 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
         for (int qb = 0; qb < nq;) {
             const int rem = nq - qb;
             const uint8_t *sp = pool + payload_off;
-            float *bq = box + qb * elems;
-#define WG_FILL(U_) { if (chk) box_fill<U_, true>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); \
-                      else box_fill<U_, false>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); qb += U_; }
+            float *bq = box + qb * elems * (WG_CELL ? 2 : 1);
+#define WG_FILL(U_) { if (chk) box_fill<U_, true, false, WG_CELL != 0>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); \
+                      else box_fill<U_, false, false, WG_CELL != 0>(sp, lane_stride, lane_index, lb + qb, row_stride, rows, cols, mnx, mny, bw, bp, bh, elems, wvs, lane, bq, WG_SWZ ? pp : 0); qb += U_; }
             if (rem >= 8 && WG_FILL_U >= 8) WG_FILL(8)
             else if (rem >= 4 && WG_FILL_U >= 4) WG_FILL(4)
             else if (rem >= 2 && WG_FILL_U >= 2) WG_FILL(2)
@@ -551,6 +560,19 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
         __syncthreads();
         uint8_t *dq = dst + (int64_t)lb * u8_lane_stride;          // this thread's dword in scan lb, advanced per scan
         for (int q = 0; q < nq; q++) {
+            float vq[4];
+#if WG_CELL
+            // cells: (s00, s10) and (s01, s11) are two neighbouring 8-byte cells - one ds_read2_b64 per pixel
+            const f32x2 *cb = reinterpret_cast<const f32x2 *>(box) + q * elems;
+            f32x2 ta[4], tb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ta[j] = cb[off0[j]]; tb[j] = cb[off0[j] + 1]; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x2 pa = ta[j] * f32x2{w00[j], w10[j]}, pb = tb[j] * f32x2{w01[j], w11[j]};      // (s00 w00, s10 w10), (s01 w01, s11 w11)
+                vq[j] = __fadd_rn(__fadd_rn(__fadd_rn(pa.x, pb.x), pa.y), pb.y);
+            }
+#else
             const float *bx = box + q * elems;
             f32x2 ta[4], tb[4];
 #pragma unroll
@@ -560,12 +582,12 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const uint32_t *__rest
             }
             // the products are formed two at a time (v_pk_mul_f32: IEEE multiplies, no fusion); the
             // sums keep the reference order ((s00 w00 + s01 w01) + s10 w10) + s11 w11
-            float vq[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const f32x2 pa = ta[j] * wa[j], pb = tb[j] * wb[j];
                 vq[j] = __fadd_rn(__fadd_rn(__fadd_rn(pa.x, pa.y), pb.x), pb.y);
             }
+#endif
             // (scalar multiplies here: a packed one makes the compiler pack the three adds above as well, at the
             // price of a dozen register moves)
             // (v_cvt_pk_u8_f32 would convert AND place the byte, but it ROUNDS to nearest where the reference's cast truncates - 11.0 ->
