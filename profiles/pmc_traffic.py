@@ -24,7 +24,7 @@ def collect(counter):
 
 C = {c: collect(c) for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_MISS_sum", "TCC_HIT_sum", "TCC_EA0_RDREQ_sum", "TCP_TCC_READ_REQ_sum",
                              "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")}
-IMAGE_FRACTION = 0.8770                       # needed tiles / all tiles of the 2024 x 2024 image (engine: rt_image_px)
+IMAGE_FRACTION = 0.8770                       # needed tiles / all tiles of the 2024 x 2024 image (engine: rt_image_px; 0.8789 with the 32-row tiles of -DRI_ROWS=32)
 ALGO = {"rt_det_strip_kernel": ("retrack.hip", IMAGE_FRACTION * 2024 * 2024 * 8.0,
                                 "float64 integral image marched in 62-column strips through an LDS ring: memory-side reads {ratio:.2f} x the algorithmic bytes "
                                 "(L2 hit rate {hit:.0%} on the lines neighbouring strips share); VALU issue, LDS array and HBM each about half busy - "

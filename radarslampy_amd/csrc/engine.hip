@@ -845,7 +845,7 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
         (void)hipHostFree(stage);
         if (!okp || ec != hipSuccess) { ROAM_SET_ERR(ctx, "retrack: phase list (%s)", ec != hipSuccess ? hipGetErrorString(ec) : "image too large"); roam_engine_destroy(ctx); return ec != hipSuccess ? ROAM_E_HIP : ROAM_E_ARG; }
         for (uint32_t i = 0; i < ph[0]; i++) {
-            const int band = (int)(ph[1 + i] & 255u), g = (int)((ph[1 + i] >> 8) & 15u), hrows = std::min(16, e->W - 16 * band);
+            const int br = retrack_band_rows(), band = (int)(ph[1 + i] & 255u), g = (int)((ph[1 + i] >> 8) & 15u), hrows = std::min(br, e->W - br * band);
             for (int w = 0; w < 4; w++)
                 if ((ph[1 + i] >> (12 + w)) & 1u) e->rt_image_px += (int64_t)hrows * std::max(0, std::min(64, e->W - (g * 256 + 64 * w)));
         }

@@ -77,6 +77,7 @@ size_t retrack_boxtab_words(int W);
 // the phase list of the one-sweep integral kernel from the sampling map and the determinant kernel's dark-step table (both on the HOST):
 // out = retrack_phase_words(W) uint32.  false: the image is too large for the one-sweep kernel (it is not used then)
 size_t retrack_phase_words(int W);
+int retrack_band_rows();              // rows of a band of the one-sweep integral kernel (a phase-list entry's tile height)
 bool retrack_build_phases(const uint32_t *map_host, const uint32_t *darktab_host, int W, int cols, uint32_t *out);
 hipError_t launch_retrack_boxtab(hipStream_t st, const uint32_t *map, int W, int cols, uint32_t *boxtab);
 // fills darktab (retrack_darktab_words(W) zero-initialised uint32 words) from the sampling map: geometry only, once per engine

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
 // Both cumulative sums keep NumPy's sequential order; the float64 image is written ONCE (32.8 MB per detection instead of the
 // 98.6 MB moved by the two-pass kernels above, which stay for small chunks - see rt_one_sweep - and for image sizes above 2048).
 #ifndef RI_ROWS
-#define RI_ROWS 16
+#define RI_ROWS 16                          // (32 with ONE tile buffer: see RI_SINGLE_BUF)
 #endif
 #ifndef RI_WAVES
 #define RI_WAVES 4
@@ -301,7 +301,19 @@ __global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
 #define RI_BD 4                             // batches of eight columns the row wave reads ahead of its chain
 #endif
 #define RI_TP 66                            // tile pitch in doubles: even, so that the row wave moves two columns per LDS instruction (round 6)
-#define RI_LDS_BYTES (2 * RI_WAVES * RI_ROWS * RI_TP * 8 + RI_LDS_PAD)
+// ONE tile buffer and bands of 32 rows (-DRI_SINGLE_BUF=1 -DRI_ROWS=32; round 6, late; bit-identical, NOT the default).  The row wave is
+// what a phase waits for, and an LDS instruction costs it ~20 cycles whatever its active lanes (profiles/r06_detection_experiments.txt
+// items 10, 11): with 32 rows per band it carries twice the pixels per instruction.  The tiles of a 32-row band take the LDS of two
+// buffers of 16 rows, so there is one buffer: A2(i) (column sums -> tile) | barrier | B(i) beside A1(i + 1) (the taps of the next phase:
+// registers only) | barrier | C(i) (tile -> HBM).  512 detections launched together (one round, the two workgroups of every CU in step):
+// 6.46 -> 5.5 ms; 1 024: 12.5 -> 14.0; 1 900: 23.7 -> 22.9; 2 048: 24.8 -> 25.4; in the step (1 700-2 100 detections per launch): 23.44-23.50
+// against 23.36-23.48 ms per launch, 70.4-70.7 against 70.4-70.6 ms per step - once the workgroups of a CU are out of step, nothing.
+// (One buffer with 16-row bands: 6.75 ms per 512, slower than two.)
+#ifndef RI_SINGLE_BUF
+#define RI_SINGLE_BUF 0
+#endif
+#define RI_NBUF (RI_SINGLE_BUF ? 1 : 2)
+#define RI_LDS_BYTES (RI_NBUF * RI_WAVES * RI_ROWS * RI_TP * 8 + RI_LDS_PAD)
 #ifndef RI_BOX
 #define RI_BOX 2560                         // (round 6: 1536 -> 2560, the LDS that is left at two workgroups per CU: fewer patches on the gather path, -2 %)
 #endif
@@ -491,7 +503,11 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                         const float wx1 = __fmul_rn((float)((mk >> 22) & 31), 1.f / 32.f), wx0 = __fsub_rn(1.f, wx1);
                         const float wy1 = __fmul_rn((float)(mk >> 27), 1.f / 32.f), wy0 = __fsub_rn(1.f, wy1);
                         const uint8_t *q = bx + (iy - mny) * bp + (ix - mnx);
-#ifdef RI_TAP16
+#ifdef RI_TAP_VALU
+                        // (experiment: the float32-only decode of warp.hip instead of the table - three VALU instructions against one LDS read)
+                        auto dec = [](uint32_t k) { const float kf = (float)k; return __fmaf_rn(kf, 0x1.0101020000000p-8f, __fmul_rn(kf, -0x1.fdfdfe0000000p-33f)); };
+                        const float s00 = dec(q[0]), s01 = dec(q[1]), s10 = dec(q[bp]), s11 = dec(q[bp + 1]);
+#elif defined(RI_TAP16)
                         // (experiment: the two neighbouring codes of a polar row in ONE 16-bit LDS read at any alignment)
                         const uint32_t w0 = reinterpret_cast<const RtU16 *>(q)->v, w1 = reinterpret_cast<const RtU16 *>(q + bp)->v;
                         const float s00 = lut[w0 & 255], s01 = lut[w0 >> 8], s10 = lut[w1 & 255], s11 = lut[w1 >> 8];
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         int gcur = 0;                                                      // the group whose running sums sit in acc[0]
         auto A2 = [&](int i, int band, int g) {
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
-            Tile &tl = tiles[(i & 1) * RI_WAVES + wave];
+            Tile &tl = tiles[(RI_SINGLE_BUF ? 0 : (i & 1)) * RI_WAVES + wave];
             {
                 // acc[0] is always the running sum of the CURRENT group's column: the array is rotated by one after every phase (8
                 // register moves; a group-indexed array was kept in scratch memory by the compiler: 16 MB of extra HBM writes per
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         auto C = [&](int i, int e) {
             const int band = ph_band(e), g = ph_group(e);
             const int c = g * 64 * RI_WAVES + 64 * wave + lane;
-            const Tile &tl = tiles[(i & 1) * RI_WAVES + wave];
+            const Tile &tl = tiles[(RI_SINGLE_BUF ? 0 : (i & 1)) * RI_WAVES + wave];
             const bool wanted = ((e >> (12 + wave_u)) & 1) != 0;              // does anything read this tile?
             if (c < W && wanted) {
                 double *q = S + (int64_t)band * RI_ROWS * SP + c;
@@ -568,6 +584,19 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             prefetch_box();
             if (nph > 1) fetch_ext(ph_band(e_1) * RI_GROUPS + ph_group(e_1));
             A1(0, e_1, e_2);
+#if RI_SINGLE_BUF
+#pragma unroll 1
+            for (int i = 0; i < nph; i++) {
+                const int e_4 = ph_ent(i + 4);
+                A2(i, ph_band(e_0), ph_group(e_0));
+                __syncthreads();                                           // tile i is complete: B(i) runs ..
+                if (i + 1 < nph) A1(i + 1, e_2, e_3);                      // .. beside the taps of phase i + 1 (registers only)
+                __syncthreads();                                           // B(i) is complete
+                C(i, e_0);
+                e_m1 = e_0; e_0 = e_1; e_1 = e_2; e_2 = e_3; e_3 = e_4;
+            }
+        }
+#else
             A2(0, ph_band(e_0), ph_group(e_0));
 #pragma unroll 1
             for (int i = 0; i < nph; i++) {
@@ -584,6 +613,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
         }
         __syncthreads();
         if (nph > 0) C(nph - 1, e_m1);
+#endif
     } else {
         // ------------------------------------------------------------------------------------ the row wave: B(i)
         // (s_setprio 3 for this wave - the chain a phase waits for - moves the wait from the column waves' barrier to their taps: the row wave
@@ -601,7 +631,7 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
             RI_P(6)
             if (live) {
                 const int C0 = g * 64 * RI_WAVES, ncols = min(64 * RI_WAVES, W - C0);
-                Tile *tg = tiles + (i & 1) * RI_WAVES;
+                Tile *tg = tiles + (RI_SINGLE_BUF ? 0 : (i & 1)) * RI_WAVES;
                 int j = 0;
                 if (ncols >= 16) {
                     // batches of eight columns (eight dependent float64 additions), 16-byte LDS accesses (two columns per instruction)
@@ -642,8 +672,13 @@ __global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs
                     *q = carry;
                 }
             }
+#if RI_SINGLE_BUF
+            __syncthreads();                                               // (outside the lanes' branch: one barrier per wave)
+#endif
         }
+#if !RI_SINGLE_BUF
         __syncthreads();
+#endif
     }
 #ifdef RI_PROF
     if (lane == 0 && (wave == 0 || wave == RI_WAVES)) for (int k = 0; k < 8; k++) atomicAdd(&ri_prof[k + (wave == 0 ? 0 : 8)], rip_[k]);
@@ -1979,11 +2014,13 @@ hipError_t launch_retrack_fused_tables(hipStream_t st, const uint32_t *map, int 
 // window of a lit step), so a phase that is left out has dark pixels only: the columns' running sums pass it unchanged.
 // out[0] = number of phases, out[1..] = band | group << 8 | needed-tile bits << 12 in sweep order.
 size_t retrack_phase_words(int W) { return 1 + (size_t)((W + RI_ROWS - 1) / RI_ROWS) * RI_GROUPS; }
+int retrack_band_rows() { return RI_ROWS; }
 
 bool retrack_build_phases(const uint32_t *map, const uint32_t *darktab, int W, int cols, uint32_t *out)
 {
     const int H = W, nbands = (H + RI_ROWS - 1) / RI_ROWS, ns = (W + SD_OUT - 1) / SD_OUT, nt = H / SD_T + 1, NT = RI_GROUPS * RI_WAVES;
-    static_assert(RI_ROWS == SD_T, "a band of the integral kernel is a block of the determinant kernel");
+    static_assert(RI_ROWS % SD_T == 0, "a band of the integral kernel is one or more blocks of the determinant kernel");
+    const int ndet = (H + SD_T - 1) / SD_T;
     if (nbands * RI_GROUPS > RI_PHL_MAX || nbands > 256) return false;
     std::vector<uint8_t> need((size_t)nbands * NT, 0), lit((size_t)nbands * NT, 0);
     std::vector<int> firstlit(W, H);
@@ -1999,10 +2036,10 @@ bool retrack_build_phases(const uint32_t *map, const uint32_t *darktab, int W, i
         if (t_first >= nt) continue;                                        // the strip sees nothing
         const int tb = t_first >= 1 ? ((t_first - 1) & ~3) : 0, te = std::min(nt, t_last + 2);
         const int cbase = s * SD_OUT - 1 - SD_HL, c_lo = std::max(cbase, 0), c_hi = std::min(cbase + SD_BP, W) - 1;
-        for (int j = tb; j <= te + 3 && j < nbands; j++) {
+        for (int j = tb; j <= te + 3 && j < ndet; j++) {
             const bool in_loop = j >= tb + 4;                               // (the four blocks of the prologue are always loaded)
             if (in_loop && ((T[8 + ((j - 4) >> 5)] >> ((j - 4) & 31)) & 1u)) continue;
-            for (int k = c_lo / 64; k <= c_hi / 64; k++) need[(size_t)j * NT + k] = 1;
+            for (int k = c_lo / 64; k <= c_hi / 64; k++) need[(size_t)(j * SD_T / RI_ROWS) * NT + k] = 1;
         }
     }
     int n = 0;
