@@ -313,6 +313,9 @@ __global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
 #define RI_SINGLE_BUF 0
 #endif
 #define RI_NBUF (RI_SINGLE_BUF ? 1 : 2)
+#ifndef RI_ROUND
+#define RI_ROUND 0                          // > 0: launch_retrack launches a chunk's integral images in rounds of that many workgroups
+#endif
 #define RI_LDS_BYTES (RI_NBUF * RI_WAVES * RI_ROWS * RI_TP * 8 + RI_LDS_PAD)
 #ifndef RI_BOX
 #define RI_BOX 2560                         // (round 6: 1536 -> 2560, the LDS that is left at two workgroups per CU: fewer patches on the gather path, -2 %)
@@ -356,13 +359,13 @@ extern "C" int roam_debug_integral_prof(unsigned long long *out, int reset)
 #else
 #define RI_P(k)
 #endif
-__global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs a, int first)
+__global__ __launch_bounds__(64 * (RI_WAVES + 1)) void rt_integral_kernel(RtArgs a, int first, int ls0)
 {
 #ifdef RI_PROF
     unsigned long long rip_[8] = {0}, rit_ = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __align__(16) double ri_lds[];
-    const int ls = blockIdx.x, slot = first + ls;
+    const int ls = ls0 + (int)blockIdx.x, slot = first + ls;      // (ls0: rounds of a chunk launched one after the other, RI_ROUND)
     if (slot >= *a.rt_n || !rt_one_sweep(a, first) || a.fused) return;
     typedef double Tile[RI_ROWS][RI_TP];
     Tile *tiles = reinterpret_cast<Tile *>(ri_lds);                        // [2][RI_WAVES]
@@ -2108,7 +2111,13 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
         if (W <= 2048 && a.fused && B - first >= RI_MIN_DETECTIONS) hipLaunchKernelGGL(rt_fused_kernel, dim3(P), dim3(FD_THREADS), FD_LDS_BYTES, st, a, first, 0);
         else if (W <= 2048 && B - first >= RI_MIN_DETECTIONS)               // (fewer lanes left than a one-sweep chunk needs: it would return at once)
-            hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first);
+        {
+            // RI_ROUND > 0 (experiment): the chunk's detections in ROUNDS of that many workgroups, one launch each - the workgroups of a
+            // round start together and stay in step (every detection is the same work), which the one-buffer form likes
+            const int round = RI_ROUND > 0 ? RI_ROUND : P;
+            for (int sub = 0; sub < P; sub += round)
+                hipLaunchKernelGGL(rt_integral_kernel, dim3(min(round, P - sub)), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, first, sub);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;              // (a refused launch - LDS attribute, grid - surfaces here, not after the chain)
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
@@ -2175,7 +2184,7 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a_in, int P, int wh
         return hipGetLastError();
     }
     if (which == 0) {
-        hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0);
+        hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0, 0);
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
         hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, 0);
