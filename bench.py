@@ -473,23 +473,40 @@ def _run_rank(args, D, rank, local_rank, world, rdv):
             # the number n of lanes that re-detect (only the device knows it); chunk c holds clamp(n - c * slots, 0, slots) detections,
             # and n is in the result records consumed above.  live[k] = mean duration of the busy launches, their detections on average
             # = doh_units_per_launch (the first chunk of a step overlaps the front end of later steps, the others mostly run alone)
-            slots_ = min(B // len(engs), args.retrack_slots or 2048)
+            slots_ = eng.detect_chunk()                        # detections per launch: retrack_slots, or 1 024 in the two-stream form (engine)
             nst = min(args.steps, 64)
             n_step = [stat.get("per_step", {}).get(pre + args.warmup + k, 0) for k in range(args.steps - nst, args.steps)]
             # (chunks of fewer than 200 detections take the two-pass integral kernels - three times the traffic of the one-sweep kernel
             # whose algorithmic bytes the roofline uses - so they are left out of the live average of BOTH kernels)
+            # Two-stream form (engines of >= 2 048 lanes: detect_chunk() < retrack_slots): the determinants of chunk c run on a second stream
+            # BESIDE the integral images of chunk c + 1, so a launch's duration there is that of two kernels sharing the GPU.  The live
+            # figure of a kernel is then taken from its launches that have no detection kernel beside them - the integral images of a
+            # step's FIRST chunk, the determinants of its LAST busy chunk (as every launch was until late round 6) - and the average over
+            # ALL busy launches is reported next to it (roofline.all_launches).
+            two_stream = slots_ < min(B // len(engs), args.retrack_slots or 2048)
             units_tot = 0
+            all_l = {}
             for k in knames[3:]:
                 m = eng.kernel_chunk_ms(k, nst)
                 tot, nb, units_tot = 0.0, 0, 0
+                tot_a, nb_a, units_a = 0.0, 0, 0
                 for srow, n_ in zip(m[-len(n_step):], n_step[-len(m):]):
-                    for c_ in range(min(len(srow), -(-n_ // slots_))):
+                    busy = min(len(srow), -(-n_ // slots_))
+                    for c_ in range(busy):
                         held = min(slots_, n_ - c_ * slots_)
                         if held >= 200:
-                            tot += float(srow[c_]); nb += 1; units_tot += held
+                            tot_a += float(srow[c_]); nb_a += 1; units_a += held
+                            alone = (not two_stream) or (c_ == 0 if k == "doh_integral" else c_ == busy - 1)
+                            if alone:
+                                tot += float(srow[c_]); nb += 1; units_tot += held
                 live[k] = tot / nb if nb else 0.0
-                live["doh_busy_launches"] = nb
-            live["doh_units_per_launch"] = float(units_tot) / live["doh_busy_launches"] if live.get("doh_busy_launches") else 0.0
+                if k == "doh_integral":
+                    live["doh_busy_launches"] = nb
+                    live["doh_units_per_launch"] = float(units_tot) / nb if nb else 0.0
+                if two_stream and nb_a:
+                    all_l[k] = {"avg_launch_ms": round(tot_a / nb_a, 4), "units_per_launch": round(units_a / nb_a, 1), "launches": nb_a}
+            if all_l:
+                live["doh_all_launches"] = all_l
     if comm is not None:
         dt = comm.allreduce_max(dt)                            # max over ranks (RCCL all-reduce, no torch)
 
@@ -683,7 +700,7 @@ def roofline(eng, args, B, retrack_fraction, live_all):
     guide prescribes (FETCH_SIZE tallies 128-byte requests at 64 bytes: x 2; cross-checked with TCC_MISS x 128 B), scaled to the
     detections per launch; null when the kernel's source changed after the passes were taken."""
     names = ["ingest_peaks", "warp_quantise", "pyramid"]
-    live = {k: v for k, v in live_all.items() if k not in ("doh_units_per_launch", "doh_busy_launches")}
+    live = {k: v for k, v in live_all.items() if k not in ("doh_units_per_launch", "doh_busy_launches", "doh_all_launches")}
     iso = {k: eng.time_kernel(k, args.kernel_reps) for k in names}
     per_step = {k: iso[k][0] for k in names}                       # ms of the kernel alone per step
     slots = None
@@ -740,6 +757,11 @@ def roofline(eng, args, B, retrack_fraction, live_all):
                 "frac_whole_image_bytes_as_rounds_2_to_5": round(units * (eng.cfg.rows * eng.cfg.clip * (dom == "doh_integral") + 8.0 * W_ * W_) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
                if slots and dom.startswith("doh") else {}),
             "units_per_launch": round(units, 1),
+            **({"all_launches": {"note": "two-stream form: the determinants of a chunk of 1 024 detections run beside the next chunk's integral images; "
+                                         "achieved / frac above are this kernel's launches with no detection kernel beside them (a step's first chunk), here every busy launch",
+                                 **{k: {**v, "frac": round(iso[k][1] / slots * v["units_per_launch"] / (v["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                    for k, v in live_all["doh_all_launches"].items()}}}
+               if live_all.get("doh_all_launches") and slots else {}),
             "isolated_achieved": round(iso_frac * HBM_PEAK_GBS, 2), "isolated_frac": round(iso_frac, 5),
             "kernel_ms_per_step_alone": {k: round(v, 4) for k, v in per_step.items()},
             "in_step_kernel_ms": {k: round(v, 4) for k, v in live.items()},

@@ -319,6 +319,10 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
  * chunks out of a roofline average, as bench.py does */
 int32_t roam_engine_kernel_chunk_ms(roam_ctx *ctx, const char *name, int32_t last_steps, float *ms_out, int32_t cap, int32_t *chunks,
                                     int32_t *steps_out);
+/* detections per launch ("chunk") of a detection kernel inside a step: retrack_slots - or 1 024 when an engine of >= 2 048 lanes and
+ * slots runs the determinants of a chunk on a second stream beside the next chunk's integral images (the default there; ROAM_DET_SIDE=0
+ * in the environment of roam_engine_create: off).  The chunks of roam_engine_kernel_chunk_ms are these */
+int32_t roam_engine_detect_chunk(roam_ctx *ctx, int32_t *chunk);
 /* time `reps` launches of the dominant streaming kernel (warp+quantise of all lanes) with
  * HIP events on the context stream; returns average ms per launch. */
 int32_t roam_engine_time_kernel(roam_ctx *ctx, const char *name, int32_t reps, float *avg_ms,

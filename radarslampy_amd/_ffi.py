@@ -94,6 +94,7 @@ _SIGS = {
     "roam_engine_set_features": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int32]),
     "roam_engine_kernel_avg": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_float), _P(C.c_int32)]),
     "roam_engine_kernel_chunk_ms": (C.c_int32, [_vp, C.c_char_p, C.c_int32, _P(C.c_float), C.c_int32, _P(C.c_int32), _P(C.c_int32)]),
+    "roam_engine_detect_chunk": (C.c_int32, [_vp, _P(C.c_int32)]),
     "roam_engine_map_reserve": (C.c_int32, [_vp, C.c_int32]),
     "roam_engine_map_count": (C.c_int32, [_vp, C.c_int32, _P(C.c_int32)]),
     "roam_engine_map_get": (C.c_int32, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _P(C.c_int32), _P(C.c_int32)]),

@@ -126,6 +126,8 @@ struct Engine {
     int pyr_after_emit = 0, peaks_after_emit = 0;
     hipEvent_t ev_emit2[2] = {};                    // the same moment, alternating between consecutive steps (ROAM_SWAP_WARP_PYR: the warp of step N + 2 waits for step N's)
     int swap_warp_pyr = 0;
+    RtSide det_side = {};                           // determinants of a chunk beside the next chunk's integral images (ROAM_DET_SIDE=chunk, 0: off)
+    int det_chunk() const { return (det_side.chunk > 0 && retrack_sided(rt, B, &det_side)) ? det_side.chunk : rt.slots; }     // detections per launch of a detection kernel
     int lm_side = 0;                                // ROAM_LM_SIDE=1 (experiment): the LM's workgroup form on the peaks' stream beside the wave form instead of behind it
     hipEvent_t ev_emit_last = nullptr;              // (swap experiment) the event the last step recorded there
     bool ev_int_valid = false;
@@ -595,6 +597,7 @@ int32_t roam_engine_destroy(roam_ctx *ctx)
     // every event handle starts out null, so a creation that failed half way leaks nothing
     auto kill = [](hipEvent_t &ev) { if (ev) { hipEventDestroy(ev); ev = nullptr; } };
     for (auto &ev : e->ev) kill(ev);
+    for (int i = 0; i < 4; i++) { kill(e->det_side.ev_i[i]); kill(e->det_side.ev_d[i]); }
     kill(e->ev_int); kill(e->ev_emit); kill(e->ev_emit2[0]); kill(e->ev_emit2[1]); kill(e->ev_lm[0]); kill(e->ev_lm[1]);
     kill(e->ev_join); kill(e->ev_pk0); kill(e->ev_pk1); kill(e->ev_warp); kill(e->ev_idx); kill(e->ev_peaks);
     for (int i = 0; i < 4; i++) { kill(e->ev_klt[i]); kill(e->ev_g4[i]); }
@@ -767,6 +770,9 @@ int32_t roam_engine_create(roam_ctx *ctx, const roam_engine_cfg *cfg)
             // (experiment) the warp and the pyramid trade places: the warp of step N + 2 beside step N's bookkeeping, the pyramid of step
             // N + 1 beside step N's back end (after its tracker)
             e->swap_warp_pyr = getenv("ROAM_SWAP_WARP_PYR") ? atoi(getenv("ROAM_SWAP_WARP_PYR")) : 0;
+            // the determinants of a chunk of 1 024 detections beside the next chunk's integral images (launch_retrack; +1.7 %); needs both
+            // halves of a 2 048-slot scratch.  ROAM_DET_SIDE=0: one launch of each kernel per chunk of `slots`, as until late round 6
+            e->det_side.chunk = getenv("ROAM_DET_SIDE") ? atoi(getenv("ROAM_DET_SIDE")) : ((B >= 2048 && r.slots >= 2048) ? 1024 : 0);
             e->lm_side = getenv("ROAM_LM_SIDE") ? atoi(getenv("ROAM_LM_SIDE")) : 0;      // (measured: nothing - 70.68 / 70.46 against 70.69 / 70.29 ms per step)
             if (e->warp_after_int && !e->pyr_after_int) e->pyr_after_int = 1;     // (the event is made for either)
             r.fd_halo_words = (int64_t)retrack_fused_halo_words(e->W);
@@ -1463,7 +1469,12 @@ int32_t roam_engine_step(roam_ctx *ctx, const int32_t *scan_idx)
             if (!e->ev_emit2[e->nstep & 1]) HIP_TRY(ctx, hipEventCreateWithFlags(&e->ev_emit2[e->nstep & 1], hipEventDisableTiming));
         }
         hipEvent_t emit_ev = (e->swap_warp_pyr && e->ev_emit2[e->nstep & 1]) ? e->ev_emit2[e->nstep & 1] : e->ev_emit;
-        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1, emit_ev));
+        if (e->det_side.chunk > 0 && !e->det_side.ev_i[0]) {
+            e->det_side.st = sB;
+            for (int i = 0; i < 4; i++) { HIP_TRY(ctx, hipEventCreateWithFlags(&e->det_side.ev_i[i], hipEventDisableTiming)); HIP_TRY(ctx, hipEventCreateWithFlags(&e->det_side.ev_d[i], hipEventDisableTiming)); }
+        }
+        HIP_TRY(ctx, launch_retrack(st, e->rt, B, e->stage_ev ? e->rt_ev[e->nstep & 63] : nullptr, RT_TRACE_CHUNKS, e->pyr_after_int ? e->ev_int : nullptr, e->pyr_after_int - 1, emit_ev,
+                                    e->det_side.chunk > 0 ? &e->det_side : nullptr));
         if (e->swap_warp_pyr) e->ev_emit_last = emit_ev;
         if (e->pyr_after_int) e->ev_int_valid = true;
         if (e->rt_mode == 2) e->rt_floor = std::min(KS, e->kmax() + 256);
@@ -1658,6 +1669,16 @@ int32_t roam_engine_kernel_avg(roam_ctx *ctx, const char *name, int32_t last_ste
     return ROAM_OK;
 }
 
+// detections per launch of a detection kernel inside a step (retrack_slots, or the chunk of the two-stream form)
+int32_t roam_engine_detect_chunk(roam_ctx *ctx, int32_t *chunk)
+{
+    ENGINE();
+    ARG_CHECK(ctx, chunk);
+    if (!e->rt_on) { ROAM_SET_ERR(ctx, "engine created without retrack_on_device"); return ROAM_E_STATE; }
+    *chunk = e->det_chunk();
+    return ROAM_OK;
+}
+
 // launch durations of a detection kernel, chunk by chunk: ms_out[s * chunks + c] = chunk c of the s-th of the last `steps_out`
 // steps (oldest first; -1 for a step without device-side detection).  A step launches `chunks` = ceil(lanes / retrack_slots) chunks
 // (at most RT_TRACE_CHUNKS are traced) whatever the number of lanes that re-detect - only the device knows it - and chunk c holds
@@ -1673,7 +1694,7 @@ int32_t roam_engine_kernel_chunk_ms(roam_ctx *ctx, const char *name, int32_t las
     if (!e->stepped) { ROAM_SET_ERR(ctx, "run a step first"); return ROAM_E_STATE; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t n = std::min<int64_t>(std::min<int64_t>(last_steps, e->nstep), 64);
-    const int nchunk = std::min((e->B + e->rt.slots - 1) / e->rt.slots, RT_TRACE_CHUNKS);
+    const int nchunk = std::min((e->B + e->det_chunk() - 1) / e->det_chunk(), RT_TRACE_CHUNKS);
     ARG_CHECK(ctx, (int64_t)cap >= n * nchunk);
     for (int64_t i = e->nstep - n, s = 0; i < e->nstep; i++, s++)
         for (int c = 0; c < nchunk; c++) {

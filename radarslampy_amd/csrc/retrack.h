@@ -62,7 +62,11 @@ hipError_t launch_retrack_collect(hipStream_t st, const roam_lane_result *res, c
 // trace (optional): three events per chunk (the first ntrace chunks), recorded around its kernels - before the integral image, between
 // it and the determinants, after the determinants (live kernel durations for bench.py's roofline)
 #define RT_TRACE_CHUNKS 16
-hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace = nullptr, int ntrace = 0, hipEvent_t after_integral = nullptr, int after_det = 0, hipEvent_t after_emit = nullptr);
+// (ROAM_DET_SIDE) the determinants of chunk c on a second stream beside the integral images of chunk c + 1: chunks of `chunk`
+// detections, the integral images alternating between two banks of the scratch (slots >= 2 * chunk)
+struct RtSide { hipStream_t st; hipEvent_t ev_i[4], ev_d[4]; int chunk; };
+bool retrack_sided(const RtArgs &a, int B, const RtSide *side);      // does launch_retrack take that form for this engine?
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace = nullptr, int ntrace = 0, hipEvent_t after_integral = nullptr, int after_det = 0, hipEvent_t after_emit = nullptr, const RtSide *side = nullptr);
 hipError_t launch_ssc_batch(hipStream_t st, const double *kp, int64_t kp_stride, const int32_t *count, int kp_cap, int P,
                             int num_ret, double tol, int cols, int rows, int32_t *work, int32_t *sel, int32_t *n_sel,
                             const int32_t *n_active, int first);

@@ -2096,7 +2096,12 @@ static hipError_t launch_det(hipStream_t st, const RtArgs &a, int first, int P)
     return hipGetLastError();
 }
 
-hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace, hipEvent_t after_integral, int after_det, hipEvent_t after_emit)
+bool retrack_sided(const RtArgs &a, int B, const RtSide *side)
+{
+    return side && side->chunk > 0 && a.W <= 2048 && !a.fused && a.slots >= 2 * side->chunk && B > side->chunk;
+}
+
+hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *trace, int ntrace, hipEvent_t after_integral, int after_det, hipEvent_t after_emit, const RtSide *side)
 {
     const int W = a.W, R = a.slots;
     // image-scale kernels chunk by chunk (the float64 integral images of `slots` detections are resident at once); the
@@ -2104,6 +2109,38 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
     // chunk: 1.4-2.7 ms of a near-idle GPU each time)
     // (the candidate counts are zero on entry: rt_append_kernel, the last kernel of this chain, clears what a detection used)
     hipError_t e = hipSuccess;
+    const bool sided = retrack_sided(a, B, side);
+    if (sided) {
+        // The determinants of chunk c on a second stream BESIDE the integral images of chunk c + 1 (round 6, late): chunks of side->chunk
+        // detections, their integral images alternating between the two halves of the scratch.  The two kernels are latency-bound chains
+        // at 10 % VALU / LDS utilisation each, and one workgroup of each per CU (80 + 74 KB of LDS) is a better pairing than two of a kind:
+        // 70.3-70.7 -> 69.2-69.3 ms per step with chunks of 1 024 (768: nothing, 640: worse); same candidates (profiles/det_side_check.py).
+        const int C = side->chunk;
+        int nc = 0;
+        for (int first = 0; first < B; first += C, nc++) {
+            const int P = min(C, B - first);
+            const bool tr = trace && nc < ntrace;
+            hipEvent_t *tev = trace + 3 * nc;
+            RtArgs ac = a;
+            ac.S = a.S + (size_t)(nc & 1) * C * a.SP * W;
+            if (nc >= 2 && (e = hipStreamWaitEvent(st, side->ev_d[(nc - 2) & 3], 0)) != hipSuccess) return e;      // this bank's determinants are done
+            if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
+            if (B - first >= RI_MIN_DETECTIONS) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, ac, first, 0);
+            const int P2 = min(P, RT_TWO_PASS_SLOTS);
+            hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, ac, first);
+            hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, ac, first);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
+            if ((e = hipEventRecord(side->ev_i[nc & 3], st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(side->st, side->ev_i[nc & 3], 0)) != hipSuccess) return e;
+            if ((e = launch_det(side->st, ac, first, P)) != hipSuccess) return e;
+            if (tr && (e = hipEventRecord(tev[2], side->st)) != hipSuccess) return e;      // (tev[1] .. tev[2]: the determinants, from the moment they could start)
+            if ((e = hipEventRecord(side->ev_d[nc & 3], side->st)) != hipSuccess) return e;
+        }
+        for (int k = max(0, nc - 2); k < nc; k++)
+            if ((e = hipStreamWaitEvent(st, side->ev_d[k & 3], 0)) != hipSuccess) return e;
+        if (after_integral && after_det <= 1 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;
+    } else
     for (int first = 0; first < B; first += R) {
         const int P = min(R, B - first);
         const bool tr = trace && first / R < ntrace;

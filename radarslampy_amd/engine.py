@@ -243,6 +243,12 @@ class Engine:
         self.ctx.check(self.lib.roam_engine_kernel_avg(self.ctx.h, name.encode(), int(last_steps), C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def detect_chunk(self) -> int:
+        """detections per launch of a detection kernel inside a step (roam_engine_detect_chunk): the chunks of kernel_chunk_ms"""
+        n = C.c_int32(0)
+        self.ctx.check(self.lib.roam_engine_detect_chunk(self.ctx.h, C.byref(n)))
+        return n.value
+
     def kernel_chunk_ms(self, name: str, last_steps: int):
         """(steps, chunks) float32 array: launch duration in ms of every detection chunk of the last steps, oldest first
         (-1: the step ran without device-side detection) - roam_engine_kernel_chunk_ms"""
