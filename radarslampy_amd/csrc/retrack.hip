@@ -109,17 +109,23 @@ __device__ __forceinline__ float rt_pixel(uint32_t m, const uint8_t *__restrict_
 // all 16 map words leave at once, then all 64 taps, the quarters' totals meet in LDS; the workgroup writes the band-local sums and the
 // band's total; the last workgroup of a column group turns the totals into what lies above each band, and the row pass adds that in as
 // it loads (all exact = NumPy's values).
+#define RT_TWO_PASS_Z 8                      // detections of a chunk the two-pass kernels work on at a time (grid z / y)
 #define RC_BAND 64
 #define RC_Q 16                              // rows per thread: RC_BAND / 4
-__global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
+__global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first, int P)
 {
-    const int ls = blockIdx.z, slot = first + ls;
-    if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
+    // (the detections of the chunk are walked gridDim.z at a time: a grid of one slab per possible detection was 204 800 workgroups per
+    // chunk that only returned whenever the chunk belonged to the one-sweep kernel or was empty - 1 to 9 ms of dispatch beside other kernels)
+    const int nls = rt_one_sweep(a, first) ? 0 : min(min(RT_TWO_PASS_SLOTS, P), *a.rt_n - first);      // (P: the chunk's scratch slots)
+    if ((int)blockIdx.z >= nls) return;
     __shared__ double tot[4][64];
     __shared__ float lut[256];
+    __shared__ int last_s;
     lut[threadIdx.x] = rt_code_to_f32(threadIdx.x);
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, W = a.W, band = blockIdx.y, nb = (W + RC_BAND - 1) / RC_BAND;
+    for (int ls = blockIdx.z; ls < nls; ls += (int)gridDim.z) {
+    const int slot = first + ls;
     const uint8_t *p = a.pool + (int64_t)a.rt_scan[slot] * a.rec_bytes + a.payload_off;
     double *S = a.S + (int64_t)ls * a.SP * W;
     const int rows = a.rows, cols = a.cols, stride = a.stride;
@@ -149,12 +155,11 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
     // time (one round trip instead of one per band).  col_done[detection][column group] counts the finished bands and is left at zero.
     // The totals cross between workgroups - between XCDs, each with an L2 of its own - as device-scope atomic stores and loads, the
     // counter after them: a __threadfence() here writes the XCD's whole L2 back, 32 MB of integral image included (151 us instead of 18).
-    __shared__ int last_s;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) last_s = atomicAdd(a.col_done + ls * 64 + (int)blockIdx.x, 1) == nb - 1;
     __syncthreads();
-    if (!last_s) return;
+    if (last_s) {
     if (q == 0 && c < W) {
         double *T = a.colT + (int64_t)ls * nb * W + c;
         double run = 0.0;
@@ -168,6 +173,9 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
         }
     }
     if (threadIdx.x == 0) a.col_done[ls * 64 + (int)blockIdx.x] = 0;
+    }
+    __syncthreads();                                   // (tot / last_s are the next detection's)
+    }
 }
 
 // Row pass: a workgroup per 16 rows; 16 lanes of wave 0, lane = row, walk sequentially along the row (the reference's summation order);
@@ -181,17 +189,18 @@ __global__ __launch_bounds__(256) void rt_integ_cols_kernel(RtArgs a, int first)
 #define RR_DEPTH 4
 #define RR_ROWS 16
 #define RR_COLS 256
-__global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
+__global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first, int P)
 {
     static_assert(RC_BAND % RR_ROWS == 0, "the rows of a workgroup lie in one band of the column pass");
     // (one buffer: a thread stores, and then overwrites, its own elements only; a row pitch of 258 doubles: every access below is a 16-byte one,
     // and the 16 chain lanes - 4 banks each, 4 apart - cover the 64 banks exactly)
     __shared__ __align__(16) double tile[RR_ROWS][RR_COLS + 2];
-    const int ls = blockIdx.y, slot = first + ls;
-    if (slot >= *a.rt_n || rt_one_sweep(a, first)) return;
+    const int nls = rt_one_sweep(a, first) ? 0 : min(min(RT_TWO_PASS_SLOTS, P), *a.rt_n - first);      // (P: the chunk's scratch slots)      // (as in the column pass: gridDim.y detections at a time)
+    if ((int)blockIdx.y >= nls) return;
     const int W = a.W, H = a.W, nb = (W + RC_BAND - 1) / RC_BAND;
-    double *S = a.S + (int64_t)ls * a.SP * W;          // (rows are 128-byte aligned: SP is a multiple of 16)
     const int r0 = blockIdx.x * RR_ROWS;
+    for (int ls = blockIdx.y; ls < nls; ls += (int)gridDim.y) {
+    double *S = a.S + (int64_t)ls * a.SP * W;          // (rows are 128-byte aligned: SP is a multiple of 16)
     const double *T = a.colT + ((int64_t)ls * nb + r0 / RC_BAND) * W;     // column sums of the bands above this one
     // a lane moves PAIRS of columns (16-byte loads and stores: 18 memory instructions per tile and lane, so that RR_DEPTH - 1 tiles in
     // flight stay below the 64 a wave can have outstanding): 128 lanes per row, 2 rows per instruction of the workgroup
@@ -266,6 +275,8 @@ __global__ __launch_bounds__(256) void rt_integ_rows_kernel(RtArgs a, int first)
 #pragma unroll
     for (int d = 0; d < RR_DEPTH - 1; d++)
         if (i0 + d < ntiles) step(reg[d], off[d], i0 + d);
+    __syncthreads();                                   // (the tile is the next detection's)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K1+K2 fused: one sweep
@@ -2127,8 +2138,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
             if (tr && (e = hipEventRecord(tev[0], st)) != hipSuccess) return e;
             if (B - first >= RI_MIN_DETECTIONS) hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, ac, first, 0);
             const int P2 = min(P, RT_TWO_PASS_SLOTS);
-            hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, ac, first);
-            hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, ac, first);
+            hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, min(P2, RT_TWO_PASS_Z)), dim3(256), 0, st, ac, first, P2);
+            hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, min(P2, RT_TWO_PASS_Z)), dim3(256), 0, st, ac, first, P2);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
             if ((e = hipEventRecord(side->ev_i[nc & 3], st)) != hipSuccess) return e;
@@ -2158,8 +2169,8 @@ hipError_t launch_retrack(hipStream_t st, const RtArgs &a, int B, hipEvent_t *tr
         if ((e = hipGetLastError()) != hipSuccess) return e;              // (a refused launch - LDS attribute, grid - surfaces here, not after the chain)
         // (the two-pass form of chunks below RI_MIN_DETECTIONS detections; its band totals live in a.colT, RT_TWO_PASS_SLOTS entries)
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, first);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, first);
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, min(P2, RT_TWO_PASS_Z)), dim3(256), 0, st, a, first, P2);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, min(P2, RT_TWO_PASS_Z)), dim3(256), 0, st, a, first, P2);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (tr && (e = hipEventRecord(tev[1], st)) != hipSuccess) return e;
         if (after_integral && !after_det && first == 0 && (e = hipEventRecord(after_integral, st)) != hipSuccess) return e;      // (the pyramid of a later step may wait for it)
@@ -2223,8 +2234,8 @@ hipError_t launch_retrack_part(hipStream_t st, const RtArgs &a_in, int P, int wh
     if (which == 0) {
         hipLaunchKernelGGL(rt_integral_kernel, dim3(P), dim3(64 * (RI_WAVES + 1)), RI_LDS_BYTES, st, a, 0, 0);
         const int P2 = min(P, RT_TWO_PASS_SLOTS);
-        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, P2), dim3(256), 0, st, a, 0);
-        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, P2), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(rt_integ_cols_kernel, dim3((W + 63) / 64, (W + RC_BAND - 1) / RC_BAND, min(P2, RT_TWO_PASS_Z)), dim3(256), 0, st, a, 0, P2);
+        hipLaunchKernelGGL(rt_integ_rows_kernel, dim3((W + RR_ROWS - 1) / RR_ROWS, min(P2, RT_TWO_PASS_Z)), dim3(256), 0, st, a, 0, P2);
     } else {
         return launch_det(st, a, 0, P);                                     // (the caller clears the candidate counts: no bookkeeping follows that would)
     }
